@@ -1,0 +1,15 @@
+"""MI355X-native time-stepping path of EnergyBalanceModel.jl (MIZ and classic models).
+
+Host-side mirror of the reference's ``step!`` / ``integrate`` surface over hand-written HIP
+kernels reached through the C ABI of ``include/ebm_hip.h``.  See DESIGN.md.
+"""
+from ._lib import EBMError, LIB_PATH, EXPORTS  # noqa: F401
+from .engine import Engine, cos2pit  # noqa: F401
+from .infrastructure import (  # noqa: F401
+    Collection, SpaceTime, Forcing, Solutions, default_parval, miz_paramset, classic_paramset,
+    default_parameters, step_, integrate, reset_step_state, classic_time_index,
+    MIZ_SOLVARS, CLASSIC_SOLVARS,
+)
+from .ensemble import EnsembleRun, shard_columns, gather_columns, hemispheric_mean  # noqa: F401
+
+Vec = "numpy.ndarray[float64]"  # the reference's Vec = Vector{Float64} (src/infrastructure.jl:13)

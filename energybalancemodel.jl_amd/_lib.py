@@ -1,0 +1,89 @@
+"""ctypes binding of the C ABI in include/ebm_hip.h (libebm_hip.so, built in-tree by
+``csrc/Makefile`` / ``__graft_entry__.build()``).
+
+This is the only compute path of the package: if the shared library is missing or no GPU is
+present the calls fail loudly — there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libebm_hip.so")
+
+# enum ebm_model / ebm_grid / ebm_field / ebm_param (include/ebm_hip.h)
+MODEL = {"MIZ": 0, "Classic": 1}
+GRID = {"identity": 0, "nonuniform": 1}
+FIELD = {"Ei": 0, "Ew": 1, "h": 2, "D": 3, "phi": 4, "T0": 5, "Tw": 6, "Ti": 7, "n": 8,
+         "E": 9, "T": 10, "Tg": 11}
+PARAM_ORDER = ("D", "A", "B", "cw", "S0", "S1", "S2", "a0", "a2", "ai", "Fb", "k", "Lf", "F",
+               "cg", "tau", "Tm", "m1", "m2", "alpha", "rl", "Dmin", "Dmax", "hmin", "kappa")
+EXPORTS = (
+    "ebm_create", "ebm_destroy", "ebm_last_error", "ebm_version", "ebm_set_field",
+    "ebm_get_field", "ebm_field_device_ptr", "ebm_set_column_forcing", "ebm_set_time_table",
+    "ebm_step", "ebm_run", "ebm_integrate", "ebm_sync", "ebm_get_counters",
+    "ebm_reset_counters", "ebm_timer_start", "ebm_timer_stop", "ebm_launch_info",
+)
+
+_dp = C.POINTER(C.c_double)
+_lib = None
+
+
+class EBMError(RuntimeError):
+    """A C-ABI call returned a negative ebm_status."""
+
+
+def load():
+    """Load libebm_hip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EBMError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C csrc); "
+            "this package has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    lib.ebm_last_error.restype = C.c_char_p
+    lib.ebm_version.restype = C.c_char_p
+    lib.ebm_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp,
+                               C.c_double, C.c_int]
+    lib.ebm_destroy.argtypes = [C.c_void_p]
+    lib.ebm_set_field.argtypes = [C.c_void_p, C.c_int, _dp]
+    lib.ebm_get_field.argtypes = [C.c_void_p, C.c_int, _dp]
+    lib.ebm_field_device_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_longlong)]
+    lib.ebm_set_column_forcing.argtypes = [C.c_void_p, _dp]
+    lib.ebm_set_time_table.argtypes = [C.c_void_p, C.c_int, _dp]
+    lib.ebm_step.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int]
+    lib.ebm_run.argtypes = [C.c_void_p, C.c_longlong, C.c_int, _dp, C.c_int]
+    lib.ebm_integrate.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, C.POINTER(C.c_int), _dp, _dp, _dp, _dp]
+    lib.ebm_sync.argtypes = [C.c_void_p]
+    lib.ebm_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    lib.ebm_reset_counters.argtypes = [C.c_void_p]
+    lib.ebm_timer_start.argtypes = [C.c_void_p]
+    lib.ebm_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.ebm_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().ebm_last_error().decode()
+        raise EBMError(f"{what} failed (status {rc}): {msg}")
+
+
+def dptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def as_f64(a, shape=None):
+    out = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and out.shape != tuple(shape):
+        raise ValueError(f"expected array of shape {tuple(shape)}, got {out.shape}")
+    return out

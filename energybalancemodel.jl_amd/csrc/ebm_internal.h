@@ -1,0 +1,79 @@
+// Internal declarations shared by the HIP kernels (ebm_kernels.hip) and the host runtime
+// behind the C ABI (ebm_runtime.hip).  Not part of the public interface (include/ebm_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ebm {
+
+// Parameter block passed to kernels by value.  The first 25 entries mirror default_parval
+// (reference src/infrastructure.jl:407-433); the derived constants are evaluated once on the
+// host in the reference's operation order so that every cell sees the same rounded value.
+struct Params {
+    double D, A, B, cw, S0, S1, S2, a0, a2, ai, Fb, k, Lf, F, cg, tau, Tm, m1, m2, alpha, rl,
+        Dmin, Dmax, hmin, kappa;
+    // MIZ
+    double Tm_pow_m2;   // Tm^m2                                   src/miz.jl:71
+    double c_latmelt;   // -pi/2.0*alpha                           src/miz.jl:141
+    double c_dn;        // Lf*alpha*Dmin^2*hmin                    src/miz.jl:127
+    double c_weld;      // kappa*alpha/4                           src/miz.jl:143
+    double c_ht;        // -1/Lf                                   src/miz.jl:139
+    double two_rl;      // 2.0*rl                                  src/miz.jl:91
+    // classic (get_statics, src/classic.jl:18-29)
+    double cg_tau, dt_tau, dc, M, kLf;
+};
+
+// Per-latitude constant vectors (device pointers, nlat doubles each).
+struct Geometry {
+    const double *x;
+    // physics stencil, bit-exact restatement of the reference's expressions:
+    //   identity grid: g0,g1,g2 = sub, diag, sup of par.D*get_diffop  (infrastructure.jl:480-497)
+    //   other grids:   g0..g4   = mxxph, mxxmh, diffx[i], diffx[i-1], phmmh  (:509-518)
+    const double *g0, *g1, *g2, *g3, *g4;
+    // same operator as plain tridiagonal coefficients; used by the T0 / Tg solves only
+    const double *lo, *di, *up;
+    // classic: kappa's three diagonals, aw, S base (src/classic.jl:21-28)
+    const double *ksub, *kdiag, *ksup, *aw, *Sb;
+};
+
+struct MizArgs {
+    double *Ei, *Ew, *h, *D, *phi, *T0;   // prognostics + warm start, [ncol][pitch]
+    double *Tw, *Ti, *n, *E, *T;          // diagnostics
+    Geometry g;
+    const double *fcol;                   // per-column forcing offset or nullptr
+    long long pitch;
+    int nlat, ncol;
+    double ct, ft, dt;
+    int write_diag;
+    unsigned long long *counters;         // 64 shards x {solves, cap hits}
+    Params p;
+};
+
+struct ClassicArgs {
+    double *E, *Tg, *T, *h;
+    Geometry g;
+    const double *fcol;
+    long long pitch;
+    int nlat, ncol;
+    double ct_i, ct_ip1, ft, dt;
+    int write_diag;
+    Params p;
+};
+
+struct LaunchCfg {
+    int threads;        // workgroup size (multiple of 64)
+    int cells;          // cells per thread (C)
+    size_t lds_bytes;   // dynamic LDS per workgroup
+};
+
+constexpr int kCounterShards = 64;
+constexpr int kMaxNewton = 50;
+
+LaunchCfg choose_launch(int nlat);
+hipError_t prepare_kernels();   // raises dynamic-LDS limits; call once per process/device
+hipError_t launch_miz_step(const MizArgs &a, int grid_kind, const LaunchCfg &cfg, hipStream_t s);
+hipError_t launch_classic_step(const ClassicArgs &a, const LaunchCfg &cfg, hipStream_t s);
+// savesol! helpers: dst[i] = src[i] (snapshot) / sum[i] += src[i] / dst[i] = sum[i]/nt; sum[i] = 0
+hipError_t launch_accumulate(double *sum, const double *src, size_t n, hipStream_t s);
+hipError_t launch_finish_mean(double *dst, double *sum, double nt, size_t n, hipStream_t s);
+
+}  // namespace ebm

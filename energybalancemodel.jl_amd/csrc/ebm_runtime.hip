@@ -1,0 +1,489 @@
+// Host runtime behind the C ABI of include/ebm_hip.h: handle/state ownership, per-latitude
+// constant tables, the step / run / integrate drivers and HIP-event timing.  Device work is in
+// ebm_kernels.hip.  There is deliberately no CPU fallback: without a GPU every entry point
+// fails with EBM_ERR_NO_DEVICE.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ebm_hip.h"
+#include "ebm_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(EBM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+}  // namespace
+
+struct ebm_ctx {
+    int model = 0, grid = 0, nlat = 0, ncol = 0, device = 0;
+    long long pitch = 0;
+    double dt = 0.0;
+    ebm::Params p{};
+    ebm::Geometry g{};
+    ebm::LaunchCfg cfg{};
+    std::vector<double *> dev_tables;              // owned device allocations (geometry)
+    double *field[EBM_F_COUNT] = {nullptr};
+    double *fcol = nullptr;
+    std::vector<double> ttab;                      // cos(2*pi*t_i), host copy
+    unsigned long long *counters = nullptr;        // device, kCounterShards x 2
+    long long n_steps = 0, n_launches = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+bool has_field(const ebm_ctx *h, int f) {
+    if (h->model == EBM_MODEL_MIZ) return f >= EBM_F_Ei && f <= EBM_F_T;
+    return f == EBM_F_E || f == EBM_F_Tg || f == EBM_F_T || f == EBM_F_h;
+}
+
+// Upload a per-latitude table padded with zeros to `padded` entries.
+int upload_table(ebm_ctx *h, const std::vector<double> &v, size_t padded, const double **out) {
+    std::vector<double> tmp(padded, 0.0);
+    std::memcpy(tmp.data(), v.data(), sizeof(double) * v.size());
+    double *d = nullptr;
+    HIPCHK(hipMalloc(&d, sizeof(double) * padded));
+    h->dev_tables.push_back(d);
+    HIPCHK(hipMemcpy(d, tmp.data(), sizeof(double) * padded, hipMemcpyHostToDevice));
+    *out = d;
+    return EBM_OK;
+}
+
+// Per-latitude constants.  Same expressions, in the same order, as the reference:
+// get_diffop (src/infrastructure.jl:480-492), the non-uniform cache (:509-518) and
+// get_statics (src/classic.jl:18-29).
+int build_tables(ebm_ctx *h, const double *x) {
+    const int nx = h->nlat;
+    const size_t padded = (size_t)h->cfg.threads * h->cfg.cells + 2;
+    const ebm::Params &p = h->p;
+    std::vector<double> xv(x, x + nx), g0(nx), g1(nx), g2(nx), g3(nx, 0.0), g4(nx, 0.0), lo(nx), di(nx), up(nx);
+    const bool uniform = (h->grid == EBM_GRID_IDENTITY) || (h->model == EBM_MODEL_CLASSIC);
+    // classic: get_statics always uses get_diffop, whatever the grid type (src/classic.jl:21)
+    const double Dscale = (h->model == EBM_MODEL_CLASSIC) ? 1.0 : p.D;
+    if (uniform) {
+        const double dx = 1.0 / nx;
+        std::vector<double> lam(nx > 1 ? nx - 1 : 0);
+        for (int i = 1; i < nx; ++i) {
+            double xb = (double)i / nx;
+            lam[i - 1] = (1.0 - xb * xb) / (dx * dx);
+        }
+        for (int k = 0; k < nx; ++k) {
+            double sub = k > 0 ? lam[k - 1] : 0.0;
+            double sup = k < nx - 1 ? lam[k] : 0.0;
+            double l1 = k > 0 ? -lam[k - 1] : 0.0;
+            double l2 = k < nx - 1 ? -lam[k] : 0.0;
+            double l3 = (-l1) - l2;
+            g0[k] = Dscale * sub;
+            g1[k] = Dscale * (-l3);
+            g2[k] = Dscale * sup;
+            lo[k] = g0[k];
+            di[k] = g1[k];
+            up[k] = g2[k];
+        }
+    } else {
+        for (int k = 0; k < nx; ++k) {
+            double xk = x[k];
+            double xm = k > 0 ? x[k - 1] : -x[0];
+            double xp = k < nx - 1 ? x[k + 1] : 2.0 - x[nx - 1];
+            double xxph = (xp + xk) / 2.0, xxmh = (xk + xm) / 2.0;
+            g0[k] = 1.0 - xxph * xxph;
+            g1[k] = 1.0 - xxmh * xxmh;
+            g2[k] = xp - xk;
+            g3[k] = xk - xm;
+            g4[k] = xxph - xxmh;
+            double u = p.D * g0[k] / (g2[k] * g4[k]);
+            double l = p.D * g1[k] / (g3[k] * g4[k]);
+            if (k == nx - 1) u = 0.0;
+            if (k == 0) l = 0.0;
+            lo[k] = l;
+            up[k] = u;
+            di[k] = -(l + u);
+        }
+    }
+    int rc;
+    if ((rc = upload_table(h, xv, padded, &h->g.x))) return rc;
+    if ((rc = upload_table(h, g0, padded, &h->g.g0))) return rc;
+    if ((rc = upload_table(h, g1, padded, &h->g.g1))) return rc;
+    if ((rc = upload_table(h, g2, padded, &h->g.g2))) return rc;
+    if ((rc = upload_table(h, g3, padded, &h->g.g3))) return rc;
+    if ((rc = upload_table(h, g4, padded, &h->g.g4))) return rc;
+    if ((rc = upload_table(h, lo, padded, &h->g.lo))) return rc;
+    if ((rc = upload_table(h, di, padded, &h->g.di))) return rc;
+    if ((rc = upload_table(h, up, padded, &h->g.up))) return rc;
+    if (h->model == EBM_MODEL_CLASSIC) {
+        std::vector<double> ksub(nx), kdiag(nx), ksup(nx), aw(nx), Sb(nx);
+        const double dtD = h->dt * p.D;
+        const double one = 1.0 + p.dt_tau;
+        for (int k = 0; k < nx; ++k) {
+            ksub[k] = 0.0 - (dtD * g0[k]) / p.cg;
+            ksup[k] = 0.0 - (dtD * g2[k]) / p.cg;
+            kdiag[k] = one - (dtD * g1[k]) / p.cg;
+            aw[k] = p.a0 - p.a2 * (x[k] * x[k]);
+            Sb[k] = p.S0 - p.S2 * (x[k] * x[k]);
+        }
+        if ((rc = upload_table(h, ksub, padded, &h->g.ksub))) return rc;
+        if ((rc = upload_table(h, kdiag, padded, &h->g.kdiag))) return rc;
+        if ((rc = upload_table(h, ksup, padded, &h->g.ksup))) return rc;
+        if ((rc = upload_table(h, aw, padded, &h->g.aw))) return rc;
+        if ((rc = upload_table(h, Sb, padded, &h->g.Sb))) return rc;
+    }
+    return EBM_OK;
+}
+
+void fill_params(ebm::Params &p, const double *v, double dt) {
+    p.D = v[EBM_P_D]; p.A = v[EBM_P_A]; p.B = v[EBM_P_B]; p.cw = v[EBM_P_cw];
+    p.S0 = v[EBM_P_S0]; p.S1 = v[EBM_P_S1]; p.S2 = v[EBM_P_S2]; p.a0 = v[EBM_P_a0];
+    p.a2 = v[EBM_P_a2]; p.ai = v[EBM_P_ai]; p.Fb = v[EBM_P_Fb]; p.k = v[EBM_P_k];
+    p.Lf = v[EBM_P_Lf]; p.F = v[EBM_P_F]; p.cg = v[EBM_P_cg]; p.tau = v[EBM_P_tau];
+    p.Tm = v[EBM_P_Tm]; p.m1 = v[EBM_P_m1]; p.m2 = v[EBM_P_m2]; p.alpha = v[EBM_P_alpha];
+    p.rl = v[EBM_P_rl]; p.Dmin = v[EBM_P_Dmin]; p.Dmax = v[EBM_P_Dmax]; p.hmin = v[EBM_P_hmin];
+    p.kappa = v[EBM_P_kappa];
+    p.Tm_pow_m2 = std::pow(p.Tm, p.m2);
+    p.c_latmelt = -M_PI / 2.0 * p.alpha;
+    p.c_dn = p.Lf * p.alpha * (p.Dmin * p.Dmin) * p.hmin;
+    p.c_weld = p.kappa * p.alpha / 4.0;
+    p.c_ht = -1.0 / p.Lf;
+    p.two_rl = 2.0 * p.rl;
+    p.cg_tau = p.cg / p.tau;
+    p.dt_tau = dt / p.tau;
+    p.dc = p.dt_tau * p.cg_tau;
+    p.M = p.B + p.cg_tau;
+    p.kLf = p.k * p.Lf;
+}
+
+int do_step(ebm_ctx *h, double ct, double ct_next, double f, int write_diag) {
+    hipError_t e;
+    if (h->model == EBM_MODEL_MIZ) {
+        ebm::MizArgs a{};
+        a.Ei = h->field[EBM_F_Ei]; a.Ew = h->field[EBM_F_Ew]; a.h = h->field[EBM_F_h];
+        a.D = h->field[EBM_F_D]; a.phi = h->field[EBM_F_phi]; a.T0 = h->field[EBM_F_T0];
+        a.Tw = h->field[EBM_F_Tw]; a.Ti = h->field[EBM_F_Ti]; a.n = h->field[EBM_F_n];
+        a.E = h->field[EBM_F_E]; a.T = h->field[EBM_F_T];
+        a.g = h->g; a.fcol = h->fcol; a.pitch = h->pitch; a.nlat = h->nlat; a.ncol = h->ncol;
+        a.ct = ct; a.ft = f; a.dt = h->dt; a.write_diag = write_diag;
+        a.counters = h->counters; a.p = h->p;
+        e = ebm::launch_miz_step(a, h->grid, h->cfg, h->stream);
+    } else {
+        ebm::ClassicArgs a{};
+        a.E = h->field[EBM_F_E]; a.Tg = h->field[EBM_F_Tg]; a.T = h->field[EBM_F_T];
+        a.h = h->field[EBM_F_h];
+        a.g = h->g; a.fcol = h->fcol; a.pitch = h->pitch; a.nlat = h->nlat; a.ncol = h->ncol;
+        a.ct_i = ct; a.ct_ip1 = ct_next; a.ft = f; a.dt = h->dt; a.write_diag = write_diag;
+        a.p = h->p;
+        e = ebm::launch_classic_step(a, h->cfg, h->stream);
+    }
+    if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+    h->n_steps += 1;
+    h->n_launches += 1;
+    return EBM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ebm_last_error(void) { return g_err.c_str(); }
+const char *ebm_version(void) { return "ebm_hip 0.1 (gfx950)"; }
+
+int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const double *x,
+               const double *params, double dt, int device) {
+    if (!out || !x || !params) return fail(EBM_ERR_ARG, "ebm_create: null argument");
+    *out = nullptr;
+    if (model != EBM_MODEL_MIZ && model != EBM_MODEL_CLASSIC) return fail(EBM_ERR_ARG, "ebm_create: unknown model");
+    if (grid != EBM_GRID_IDENTITY && grid != EBM_GRID_NONUNIFORM) return fail(EBM_ERR_ARG, "ebm_create: unknown grid kind");
+    if (nlat < 2 || ncol < 1) return fail(EBM_ERR_ARG, "ebm_create: need nlat >= 2 and ncol >= 1");
+    if (!(dt > 0.0)) return fail(EBM_ERR_ARG, "ebm_create: dt must be positive");
+    if (model == EBM_MODEL_MIZ && params[EBM_P_Tm] < 0.0 && params[EBM_P_m2] != std::floor(params[EBM_P_m2]))
+        return fail(EBM_ERR_ARG, "ebm_create: Tm^m2 with Tm < 0 and non-integer m2 (DomainError in the reference, src/miz.jl:71)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(EBM_ERR_NO_DEVICE, "ebm_create: no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(EBM_ERR_ARG, "ebm_create: device index out of range");
+    ebm::LaunchCfg cfg = ebm::choose_launch(nlat);
+    if (cfg.threads == 0) return fail(EBM_ERR_UNSUPPORTED, "ebm_create: nlat > 8192 is not supported");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(ebm::prepare_kernels());
+    ebm_ctx *h = new ebm_ctx();
+    h->model = model; h->grid = grid; h->nlat = nlat; h->ncol = ncol; h->device = device;
+    h->dt = dt; h->cfg = cfg;
+    h->pitch = (nlat + 1) / 2 * 2;
+    fill_params(h->p, params, dt);
+    int rc = build_tables(h, x);
+    if (rc) { ebm_destroy(h); return rc; }
+    const size_t nbytes = sizeof(double) * (size_t)ncol * (size_t)h->pitch;
+    for (int f = 0; f < EBM_F_COUNT; ++f) {
+        if (!has_field(h, f)) continue;
+        hipError_t e = hipMalloc(&h->field[f], nbytes);
+        if (e == hipSuccess) e = hipMemset(h->field[f], 0, nbytes);
+        if (e != hipSuccess) { ebm_destroy(h); return fail(EBM_ERR_HIP, std::string("field allocation: ") + hipGetErrorString(e)); }
+    }
+    hipError_t e = hipMalloc(&h->counters, sizeof(unsigned long long) * 2 * ebm::kCounterShards);
+    if (e == hipSuccess) e = hipMemset(h->counters, 0, sizeof(unsigned long long) * 2 * ebm::kCounterShards);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev1);
+    if (e != hipSuccess) { ebm_destroy(h); return fail(EBM_ERR_HIP, std::string("ebm_create: ") + hipGetErrorString(e)); }
+    *out = h;
+    return EBM_OK;
+}
+
+int ebm_destroy(ebm_handle_t h) {
+    if (!h) return EBM_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (double *d : h->dev_tables) (void)hipFree(d);
+    for (int f = 0; f < EBM_F_COUNT; ++f)
+        if (h->field[f]) (void)hipFree(h->field[f]);
+    if (h->fcol) (void)hipFree(h->fcol);
+    if (h->counters) (void)hipFree(h->counters);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return EBM_OK;
+}
+
+int ebm_set_field(ebm_handle_t h, int field, const double *host) {
+    if (!h || !host) return fail(EBM_ERR_ARG, "ebm_set_field: null argument");
+    if (field < 0 || field >= EBM_F_COUNT || !has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_set_field: field not part of this model");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy2D(h->field[field], sizeof(double) * h->pitch, host, sizeof(double) * h->nlat,
+                       sizeof(double) * h->nlat, h->ncol, hipMemcpyHostToDevice));
+    return EBM_OK;
+}
+
+int ebm_get_field(ebm_handle_t h, int field, double *host) {
+    if (!h || !host) return fail(EBM_ERR_ARG, "ebm_get_field: null argument");
+    if (field < 0 || field >= EBM_F_COUNT || !has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_get_field: field not part of this model");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy2D(host, sizeof(double) * h->nlat, h->field[field], sizeof(double) * h->pitch,
+                       sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToHost));
+    return EBM_OK;
+}
+
+int ebm_field_device_ptr(ebm_handle_t h, int field, double **dptr, long long *pitch) {
+    if (!h || !dptr) return fail(EBM_ERR_ARG, "ebm_field_device_ptr: null argument");
+    if (field < 0 || field >= EBM_F_COUNT || !has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_field_device_ptr: field not part of this model");
+    *dptr = h->field[field];
+    if (pitch) *pitch = h->pitch;
+    return EBM_OK;
+}
+
+int ebm_set_column_forcing(ebm_handle_t h, const double *fcol) {
+    if (!h) return fail(EBM_ERR_ARG, "ebm_set_column_forcing: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (!fcol) {
+        if (h->fcol) HIPCHK(hipFree(h->fcol));
+        h->fcol = nullptr;
+        return EBM_OK;
+    }
+    if (!h->fcol) HIPCHK(hipMalloc(&h->fcol, sizeof(double) * h->ncol));
+    HIPCHK(hipMemcpy(h->fcol, fcol, sizeof(double) * h->ncol, hipMemcpyHostToDevice));
+    return EBM_OK;
+}
+
+int ebm_set_time_table(ebm_handle_t h, int nt, const double *cos2pit) {
+    if (!h || !cos2pit || nt < 1) return fail(EBM_ERR_ARG, "ebm_set_time_table: bad argument");
+    h->ttab.assign(cos2pit, cos2pit + nt);
+    return EBM_OK;
+}
+
+int ebm_step(ebm_handle_t h, double cos2pit, double cos2pit_next, double f, int write_diag) {
+    if (!h) return fail(EBM_ERR_ARG, "ebm_step: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    return do_step(h, cos2pit, cos2pit_next, f, write_diag);
+}
+
+int ebm_run(ebm_handle_t h, long long first_step, int nsteps, const double *f_steps, int diag_last) {
+    if (!h || nsteps < 0 || first_step < 0) return fail(EBM_ERR_ARG, "ebm_run: bad argument");
+    if (h->ttab.empty()) return fail(EBM_ERR_ARG, "ebm_run: call ebm_set_time_table first");
+    HIPCHK(hipSetDevice(h->device));
+    const long long nt = (long long)h->ttab.size();
+    for (int s = 0; s < nsteps; ++s) {
+        const long long ti = (first_step + s) % nt;
+        const double f = f_steps ? f_steps[s] : 0.0;
+        int rc = do_step(h, h->ttab[ti], h->ttab[(ti + 1) % nt], f, diag_last && s == nsteps - 1);
+        if (rc) return rc;
+    }
+    return EBM_OK;
+}
+
+int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int lastonly,
+                  int winter_inx, int summer_inx, int nvars, const int *fields, double *raw,
+                  double *winter, double *summer, double *avg) {
+    if (!h || nt < 1 || dur < 1 || nvars < 0 || (nvars > 0 && !fields)) return fail(EBM_ERR_ARG, "ebm_integrate: bad argument");
+    if ((long long)h->ttab.size() != nt) return fail(EBM_ERR_ARG, "ebm_integrate: time table length must equal nt");
+    for (int v = 0; v < nvars; ++v)
+        if (fields[v] < 0 || fields[v] >= EBM_F_COUNT || !has_field(h, fields[v])) return fail(EBM_ERR_ARG, "ebm_integrate: field not part of this model");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t ncell = (size_t)h->ncol * h->nlat;          // packed cells per snapshot
+    const size_t npitch = (size_t)h->ncol * h->pitch;        // device elements per field
+    const long long total = (long long)nt * dur;
+    const long long nraw = lastonly ? nt : total;
+    // device staging for raw snapshots: [var][chunk][ncol][nlat]
+    long long chunk = 0;
+    double *stage = nullptr, *sums = nullptr, *mean = nullptr;
+    if (raw && nvars > 0) {
+        chunk = (long long)((256ull << 20) / (sizeof(double) * ncell * (size_t)nvars));
+        if (chunk < 1) chunk = 1;
+        if (chunk > nraw) chunk = nraw;
+        HIPCHK(hipMalloc(&stage, sizeof(double) * ncell * (size_t)nvars * (size_t)chunk));
+    }
+    if (avg && nvars > 0) {
+        HIPCHK(hipMalloc(&sums, sizeof(double) * npitch * (size_t)nvars));
+        HIPCHK(hipMemsetAsync(sums, 0, sizeof(double) * npitch * (size_t)nvars, h->stream));
+        HIPCHK(hipMalloc(&mean, sizeof(double) * npitch));
+    }
+    auto cleanup = [&]() {
+        if (stage) (void)hipFree(stage);
+        if (sums) (void)hipFree(sums);
+        if (mean) (void)hipFree(mean);
+    };
+    auto snapshot_to_host = [&](double *dst, const double *src_dev) -> hipError_t {
+        return hipMemcpy2DAsync(dst, sizeof(double) * h->nlat, src_dev, sizeof(double) * h->pitch,
+                                sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToHost, h->stream);
+    };
+    long long staged = 0, raw_base = 0;   // snapshots in the staging buffer; raw index of its first
+    auto flush = [&]() -> hipError_t {
+        if (!staged) return hipSuccess;
+        for (int v = 0; v < nvars; ++v) {
+            hipError_t e = hipMemcpyAsync(raw + ((size_t)v * nraw + raw_base) * ncell,
+                                          stage + (size_t)v * chunk * ncell,
+                                          sizeof(double) * ncell * (size_t)staged, hipMemcpyDeviceToHost, h->stream);
+            if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipStreamSynchronize(h->stream);
+        raw_base += staged;
+        staged = 0;
+        return e;
+    };
+#define EBM_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            cleanup();                                                                    \
+            return fail(EBM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+        }                                                                                 \
+    } while (0)
+    for (long long tinx = 1; tinx <= total; ++tinx) {              // 1-based, as the reference
+        const long long ti = (tinx - 1) % nt + 1;
+        const long long year = (tinx - 1) / nt + 1;                // ceil(st.T[tinx])
+        const double f = f_steps ? f_steps[tinx - 1] : 0.0;
+        int rc = do_step(h, h->ttab[ti - 1], h->ttab[ti % nt], f, 1);
+        if (rc) { cleanup(); return rc; }
+        // savesol!, src/infrastructure.jl:549-591
+        if (sums)
+            for (int v = 0; v < nvars; ++v)
+                EBM_TRY(ebm::launch_accumulate(sums + (size_t)v * npitch, h->field[fields[v]], npitch, h->stream));
+        if (stage && (!lastonly || tinx > total - nt)) {
+            for (int v = 0; v < nvars; ++v)
+                EBM_TRY(hipMemcpy2DAsync(stage + ((size_t)v * chunk + staged) * ncell, sizeof(double) * h->nlat,
+                                         h->field[fields[v]], sizeof(double) * h->pitch, sizeof(double) * h->nlat,
+                                         h->ncol, hipMemcpyDeviceToDevice, h->stream));
+            if (++staged == chunk) EBM_TRY(flush());
+        }
+        if (ti == winter_inx) {
+            if (winter)
+                for (int v = 0; v < nvars; ++v)
+                    EBM_TRY(snapshot_to_host(winter + ((size_t)v * dur + (year - 1)) * ncell, h->field[fields[v]]));
+        } else if (ti == summer_inx) {
+            if (summer)
+                for (int v = 0; v < nvars; ++v)
+                    EBM_TRY(snapshot_to_host(summer + ((size_t)v * dur + (year - 1)) * ncell, h->field[fields[v]]));
+        } else if (ti == nt) {
+            if (sums)
+                for (int v = 0; v < nvars; ++v) {
+                    EBM_TRY(ebm::launch_finish_mean(mean, sums + (size_t)v * npitch, (double)nt, npitch, h->stream));
+                    EBM_TRY(snapshot_to_host(avg + ((size_t)v * dur + (year - 1)) * ncell, mean));
+                    EBM_TRY(hipStreamSynchronize(h->stream));
+                }
+        }
+        if (sums && ti == nt && !(ti != winter_inx && ti != summer_inx))   // year ended on a seasonal index:
+            EBM_TRY(hipMemsetAsync(sums, 0, sizeof(double) * npitch * (size_t)nvars, h->stream));  // no mean is taken, restart sums
+    }
+    EBM_TRY(flush());
+    EBM_TRY(hipStreamSynchronize(h->stream));
+#undef EBM_TRY
+    cleanup();
+    return EBM_OK;
+}
+
+int ebm_sync(ebm_handle_t h) {
+    if (!h) return fail(EBM_ERR_ARG, "ebm_sync: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return EBM_OK;
+}
+
+int ebm_get_counters(ebm_handle_t h, long long *counters) {
+    if (!h || !counters) return fail(EBM_ERR_ARG, "ebm_get_counters: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    unsigned long long host[2 * ebm::kCounterShards];
+    HIPCHK(hipMemcpy(host, h->counters, sizeof(host), hipMemcpyDeviceToHost));
+    long long solves = 0, caps = 0;
+    for (int i = 0; i < ebm::kCounterShards; ++i) {
+        solves += (long long)host[2 * i];
+        caps += (long long)host[2 * i + 1];
+    }
+    counters[0] = h->n_steps;
+    counters[1] = solves;
+    counters[2] = caps;
+    counters[3] = h->n_launches;
+    return EBM_OK;
+}
+
+int ebm_reset_counters(ebm_handle_t h) {
+    if (!h) return fail(EBM_ERR_ARG, "ebm_reset_counters: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemset(h->counters, 0, sizeof(unsigned long long) * 2 * ebm::kCounterShards));
+    h->n_steps = 0;
+    h->n_launches = 0;
+    return EBM_OK;
+}
+
+int ebm_timer_start(ebm_handle_t h) {
+    if (!h) return fail(EBM_ERR_ARG, "ebm_timer_start: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    return EBM_OK;
+}
+
+int ebm_timer_stop(ebm_handle_t h, float *elapsed_ms) {
+    if (!h || !elapsed_ms) return fail(EBM_ERR_ARG, "ebm_timer_stop: null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
+    return EBM_OK;
+}
+
+int ebm_launch_info(ebm_handle_t h, int *info) {
+    if (!h || !info) return fail(EBM_ERR_ARG, "ebm_launch_info: null argument");
+    info[0] = h->cfg.threads;
+    info[1] = h->cfg.cells;
+    info[2] = (int)h->cfg.lds_bytes;
+    info[3] = h->ncol;
+    return EBM_OK;
+}
+
+}  // extern "C"

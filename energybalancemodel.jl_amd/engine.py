@@ -1,0 +1,159 @@
+"""Engine: a thin object wrapper over one ebm_handle_t (include/ebm_hip.h).
+
+Owns the device-resident state of ``ncol`` independent meridians (longitudes and/or ensemble
+members) of ``nlat`` cells, including the T0 warm start that the reference keeps in a
+module-level closure (reference src/miz.jl:47,64).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import FIELD, GRID, MODEL, PARAM_ORDER, as_f64, check, dptr
+
+MIZ_PROGNOSTIC = ("Ei", "Ew", "h", "D", "phi")
+MIZ_DIAGNOSTIC = ("Tw", "Ti", "n", "E", "T")
+CLASSIC_PROGNOSTIC = ("E", "Tg")
+CLASSIC_DIAGNOSTIC = ("T", "h")
+
+
+def cos2pit(t: float) -> float:
+    """cos(2.0*pi*t) exactly as the reference writes it (src/miz.jl:11, src/classic.jl:24)."""
+    return math.cos(2.0 * math.pi * t)
+
+
+def param_vector(par, defaults) -> np.ndarray:
+    get = par.get if hasattr(par, "get") else (lambda k, d: getattr(par, k, d))
+    return np.array([get(k, defaults[k]) for k in PARAM_ORDER], dtype=np.float64)
+
+
+class Engine:
+    def __init__(self, model: str, grid_kind: str, x, params25, dt: float, ncol: int = 1,
+                 device: int = 0):
+        if model not in MODEL:
+            raise ValueError(f"unknown model {model!r}: expected 'MIZ' or 'Classic'")
+        self.lib = _lib.load()
+        self.model, self.grid_kind = model, grid_kind
+        self.x = as_f64(x)
+        self.nlat, self.ncol, self.dt = int(self.x.shape[0]), int(ncol), float(dt)
+        self.params = as_f64(params25, (len(PARAM_ORDER),))
+        h = C.c_void_p()
+        gk = GRID["identity"] if grid_kind == "identity" else GRID["nonuniform"]
+        check(self.lib.ebm_create(C.byref(h), MODEL[model], gk, self.nlat, self.ncol,
+                                  dptr(self.x), dptr(self.params), self.dt, int(device)),
+              "ebm_create")
+        self._h = h
+        self.nt = None
+
+    # -- lifetime ---------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.ebm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- state ------------------------------------------------------------------------
+    @property
+    def prognostic(self):
+        return MIZ_PROGNOSTIC if self.model == "MIZ" else CLASSIC_PROGNOSTIC
+
+    @property
+    def diagnostic(self):
+        return MIZ_DIAGNOSTIC if self.model == "MIZ" else CLASSIC_DIAGNOSTIC
+
+    def set_field(self, name: str, values):
+        a = as_f64(values).reshape(self.ncol, self.nlat)
+        check(self.lib.ebm_set_field(self._h, FIELD[name], dptr(a)), f"ebm_set_field({name})")
+
+    def get_field(self, name: str) -> np.ndarray:
+        out = np.empty((self.ncol, self.nlat))
+        check(self.lib.ebm_get_field(self._h, FIELD[name], dptr(out)), f"ebm_get_field({name})")
+        return out
+
+    def set_state(self, state: dict):
+        for k, v in state.items():
+            self.set_field(k, v)
+
+    def get_state(self, names=None) -> dict:
+        names = names or (self.prognostic + self.diagnostic)
+        return {k: self.get_field(k) for k in names}
+
+    def field_device_ptr(self, name: str):
+        p, pitch = C.c_void_p(), C.c_longlong()
+        check(self.lib.ebm_field_device_ptr(self._h, FIELD[name], C.byref(p), C.byref(pitch)),
+              "ebm_field_device_ptr")
+        return p.value, pitch.value
+
+    def set_column_forcing(self, fcol):
+        a = None if fcol is None else as_f64(fcol, (self.ncol,))
+        check(self.lib.ebm_set_column_forcing(self._h, dptr(a)), "ebm_set_column_forcing")
+
+    def set_time_table(self, t_in_year):
+        """t_in_year = st.t; uploads cos(2.0*pi*t_i)."""
+        tab = np.array([cos2pit(float(t)) for t in t_in_year], dtype=np.float64)
+        self.nt = len(tab)
+        self.ttab = tab
+        check(self.lib.ebm_set_time_table(self._h, self.nt, dptr(tab)), "ebm_set_time_table")
+
+    # -- stepping ---------------------------------------------------------------------
+    def step(self, ct: float, ct_next: float, f: float, write_diag: bool = True):
+        check(self.lib.ebm_step(self._h, ct, ct_next, f, int(write_diag)), "ebm_step")
+
+    def run(self, first_step: int, nsteps: int, f_steps=None, diag_last: bool = True):
+        a = None if f_steps is None else as_f64(f_steps, (nsteps,))
+        check(self.lib.ebm_run(self._h, int(first_step), int(nsteps), dptr(a), int(diag_last)),
+              "ebm_run")
+
+    def integrate(self, nt, dur, f_steps, lastonly, winter_inx, summer_inx, names,
+                  want_raw=True, want_seasonal=True):
+        """ebm_integrate: returns dict(raw, winter, summer, avg), each [nvars, n, ncol, nlat]."""
+        nv = len(names)
+        fields = (C.c_int * nv)(*[FIELD[n] for n in names])
+        nraw = nt if lastonly else nt * dur
+        f = None if f_steps is None else as_f64(f_steps, (nt * dur,))
+        raw = np.empty((nv, nraw, self.ncol, self.nlat)) if want_raw else None
+        mk = (lambda: np.full((nv, dur, self.ncol, self.nlat), np.nan)) if want_seasonal else (lambda: None)
+        winter, summer, avg = mk(), mk(), mk()
+        check(self.lib.ebm_integrate(self._h, nt, dur, dptr(f), int(lastonly), int(winter_inx),
+                                     int(summer_inx), nv, fields, dptr(raw), dptr(winter),
+                                     dptr(summer), dptr(avg)), "ebm_integrate")
+        return dict(raw=raw, winter=winter, summer=summer, avg=avg)
+
+    def sync(self):
+        check(self.lib.ebm_sync(self._h), "ebm_sync")
+
+    # -- measurement ------------------------------------------------------------------
+    def counters(self) -> dict:
+        c = (C.c_longlong * 4)()
+        check(self.lib.ebm_get_counters(self._h, c), "ebm_get_counters")
+        return dict(steps=c[0], solves=c[1], cap_hits=c[2], launches=c[3])
+
+    def reset_counters(self):
+        check(self.lib.ebm_reset_counters(self._h), "ebm_reset_counters")
+
+    def timer_start(self):
+        check(self.lib.ebm_timer_start(self._h), "ebm_timer_start")
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        check(self.lib.ebm_timer_stop(self._h, C.byref(ms)), "ebm_timer_stop")
+        return float(ms.value)
+
+    def launch_info(self) -> dict:
+        info = (C.c_int * 4)()
+        check(self.lib.ebm_launch_info(self._h, info), "ebm_launch_info")
+        return dict(threads=info[0], cells_per_thread=info[1], lds_bytes=info[2], workgroups=info[3])

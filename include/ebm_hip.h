@@ -1,0 +1,140 @@
+/* ebm_hip.h — C ABI of the MI355X-native energy-balance time-stepping path.
+ *
+ * This is the drop-in boundary for the hot path of waylonwh/EnergyBalanceModel.jl:
+ *
+ *   Infrastructure.step!(::Val{:MIZ}|::Val{:Classic}, t, f, vars, st, par; debug, verbose)
+ *       stub   src/infrastructure.jl:594
+ *       MIZ    src/miz.jl:150-196        classic  src/classic.jl:37-71
+ *   Infrastructure.integrate(model, st, forcing, par, init; lastonly, debug, verbose)
+ *       src/infrastructure.jl:615-636 (+ savesol! :549-591, annual_mean :536-544)
+ *
+ * The reference is pure Julia and has no FFI of its own; the entry points below are what a
+ * Julia `ccall` shim binds (julia/EBMHip.jl).  Plain C: opaque handle,
+ * `double*`/`int` only, no C++/torch types.  All arrays are fp64, latitude contiguous:
+ * a field is `[ncol][nlat]` in C order == Julia `Array{Float64,2}(nlat, ncol)`; a column is
+ * one independent meridian (a longitude of a 2-D grid and/or an ensemble member).
+ *
+ * Threading: all state — including the T0 warm start the reference hides in a module-level
+ * closure (src/miz.jl:47,64) — is owned by the handle.  Different handles may be used from
+ * different host threads; one handle must not be used concurrently.
+ *
+ * Errors: every function returns 0 on success, a negative ebm_status otherwise; the message
+ * is available (per host thread) from ebm_last_error().  Numerical events are not errors:
+ * NaN sentinels are data (src/miz.jl:193-194) and a T0 iteration that hits its cap is only
+ * counted (the reference merely warns, src/miz.jl:61-63) — see ebm_get_counters.
+ */
+#ifndef EBM_HIP_H
+#define EBM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ebm_ctx *ebm_handle_t;
+
+enum ebm_status {
+    EBM_OK = 0,
+    EBM_ERR_ARG = -1,      /* bad argument */
+    EBM_ERR_HIP = -2,      /* HIP runtime error */
+    EBM_ERR_UNSUPPORTED = -3,
+    EBM_ERR_NO_DEVICE = -4 /* no usable GPU: the library never falls back to the CPU */
+};
+
+/* model tag == the Val{...} the reference dispatches step! on (src/infrastructure.jl:594) */
+enum ebm_model { EBM_MODEL_MIZ = 0, EBM_MODEL_CLASSIC = 1 };
+
+/* SpaceTime{identity} uses the sparse uniform-x operator (src/infrastructure.jl:495-497);
+ * every other SpaceTime{F} (e.g. sin) the flux-form stencil (:505-526). */
+enum ebm_grid { EBM_GRID_IDENTITY = 0, EBM_GRID_NONUNIFORM = 1 };
+
+/* order of the 25 entries of default_parval (src/infrastructure.jl:407-433) */
+enum ebm_param {
+    EBM_P_D = 0, EBM_P_A, EBM_P_B, EBM_P_cw, EBM_P_S0, EBM_P_S1, EBM_P_S2, EBM_P_a0, EBM_P_a2,
+    EBM_P_ai, EBM_P_Fb, EBM_P_k, EBM_P_Lf, EBM_P_F, EBM_P_cg, EBM_P_tau, EBM_P_Tm, EBM_P_m1,
+    EBM_P_m2, EBM_P_alpha, EBM_P_rl, EBM_P_Dmin, EBM_P_Dmax, EBM_P_hmin, EBM_P_kappa,
+    EBM_P_COUNT
+};
+
+/* fields of `vars` (src/infrastructure.jl:604-605, 621-624) plus the hidden warm start */
+enum ebm_field {
+    EBM_F_Ei = 0, EBM_F_Ew, EBM_F_h, EBM_F_D, EBM_F_phi, /* MIZ prognostics (init)          */
+    EBM_F_T0,                                             /* MIZ warm start (src/miz.jl:47)  */
+    EBM_F_Tw, EBM_F_Ti, EBM_F_n, EBM_F_E, EBM_F_T,        /* MIZ diagnostics; E,T also classic */
+    EBM_F_Tg,                                             /* classic ghost layer             */
+    EBM_F_COUNT
+};
+/* classic uses EBM_F_E, EBM_F_Tg (prognostic) and EBM_F_T, EBM_F_h (diagnostic). */
+
+/* ---- lifetime ------------------------------------------------------------------------ */
+
+/* Create a stepping context on HIP device `device` for `ncol` independent meridians of
+ * `nlat` cells.  x[nlat] is st.x, params[EBM_P_COUNT] the parameter values (entries a model
+ * does not use are ignored), dt = st.dt.  All state starts at zero (as the reference's T0
+ * warm start does).  Fails with EBM_ERR_NO_DEVICE when no GPU is present. */
+int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const double *x,
+               const double *params, double dt, int device);
+int ebm_destroy(ebm_handle_t h);
+const char *ebm_last_error(void);
+const char *ebm_version(void);
+
+/* ---- state --------------------------------------------------------------------------- */
+
+/* Copy a whole field host<->device ([ncol][nlat] doubles, synchronous). */
+int ebm_set_field(ebm_handle_t h, int field, const double *host);
+int ebm_get_field(ebm_handle_t h, int field, double *host);
+/* Device pointer of a field and its row pitch in elements (>= nlat), for zero-copy users
+ * (e.g. a torch tensor view).  The pointer stays valid until ebm_destroy. */
+int ebm_field_device_ptr(ebm_handle_t h, int field, double **dptr, long long *pitch);
+/* Per-column forcing offset added to the per-step scalar forcing (forcing = f + fcol[col];
+ * NULL clears it).  This is how ensemble members / longitudes get perturbed forcings — the
+ * reference has a single scalar `f` per step (src/infrastructure.jl:631). */
+int ebm_set_column_forcing(ebm_handle_t h, const double *fcol);
+/* Table of cos(2.0*pi*st.t[i]), i = 1..nt (src/miz.jl:11, src/classic.jl:24), needed by
+ * ebm_run/ebm_integrate.  Computed by the caller so that host and device agree bit for bit. */
+int ebm_set_time_table(ebm_handle_t h, int nt, const double *cos2pit);
+
+/* ---- stepping ------------------------------------------------------------------------ */
+
+/* One step!: cos2pit = cos(2.0*pi*t) for this step; cos2pit_next is column i+1 of the
+ * classic model's S table (src/classic.jl:25,61; ignored for MIZ); f the scalar forcing.
+ * write_diag != 0 also writes the diagnostic fields (Tw,Ti,n,E,T / T,h).  Asynchronous on
+ * the handle's stream. */
+int ebm_step(ebm_handle_t h, double cos2pit, double cos2pit_next, double f, int write_diag);
+
+/* nsteps consecutive steps, one kernel launch per step (K = 1), starting at 0-based global
+ * step index `first_step` (time-of-year index = first_step mod nt into the time table).
+ * f_steps[nsteps] are the per-step scalar forcings (NULL = 0.0).  Diagnostics are written
+ * on the last step only when diag_last != 0.  Asynchronous. */
+int ebm_run(ebm_handle_t h, long long first_step, int nsteps, const double *f_steps,
+            int diag_last);
+
+/* integrate + savesol! (src/infrastructure.jl:549-591, 615-636) with state resident on the
+ * device: runs nt*dur steps from the current state.  `fields[nvars]` selects the saved
+ * variables; outputs are host buffers (any may be NULL to skip):
+ *   raw    [nvars][nraw][ncol][nlat]   nraw = lastonly ? nt : nt*dur
+ *   winter, summer, avg  [nvars][dur][ncol][nlat]
+ * winter_inx/summer_inx are the 1-based in-year indices st.winter.inx / st.summer.inx.
+ * f_steps[nt*dur] as in ebm_run.  Synchronous. */
+int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int lastonly,
+                  int winter_inx, int summer_inx, int nvars, const int *fields, double *raw,
+                  double *winter, double *summer, double *avg);
+
+int ebm_sync(ebm_handle_t h);
+
+/* ---- measurement / diagnostics ------------------------------------------------------- */
+
+/* counters[0] steps, [1] tridiagonal solves summed over columns, [2] column-steps whose T0
+ * active-set iteration hit its cap, [3] kernel launches.  Synchronises the stream. */
+int ebm_get_counters(ebm_handle_t h, long long *counters);
+int ebm_reset_counters(ebm_handle_t h);
+/* HIP-event timing on the handle's stream (the stream the kernels are launched on). */
+int ebm_timer_start(ebm_handle_t h);
+int ebm_timer_stop(ebm_handle_t h, float *elapsed_ms);
+/* Launch geometry chosen for this handle: info[0] threads per workgroup, [1] cells per
+ * thread, [2] dynamic LDS bytes per workgroup, [3] workgroups per launch. */
+int ebm_launch_info(ebm_handle_t h, int *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EBM_HIP_H */
