@@ -69,7 +69,7 @@ constexpr int kCounterShards = 64;
 constexpr int kMaxNewton = 50;
 
 LaunchCfg choose_launch(int nlat);
-hipError_t prepare_kernels();   // raises dynamic-LDS limits; call once per process/device
+hipError_t prepare_kernels(const LaunchCfg &cfg);   // raises the dynamic-LDS limit if needed
 hipError_t launch_miz_step(const MizArgs &a, int grid_kind, const LaunchCfg &cfg, hipStream_t s);
 hipError_t launch_classic_step(const ClassicArgs &a, const LaunchCfg &cfg, hipStream_t s);
 // savesol! helpers: dst[i] = src[i] (snapshot) / sum[i] += src[i] / dst[i] = sum[i]/nt; sum[i] = 0

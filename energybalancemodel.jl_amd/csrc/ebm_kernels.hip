@@ -16,7 +16,7 @@
 //
 // Arithmetic policy.  Everything outside the tridiagonal solves is a bit-exact restatement of
 // the reference's expressions (IEEE division, no FMA contraction: build with
-// -ffp-contract=off; operation order as in oracle/ebm_oracle.c).  The solves are free to use
+// -ffp-contract=off; the order of operations is the reference's).  The solves are free to use
 // any arithmetic: their result is defined by the linear system, not by an operation order.
 //
 // No MFMA: there is no dense contraction on this path; it is HBM-/fp64-VALU-bound.
@@ -587,19 +587,24 @@ LaunchCfg choose_launch(int nlat) {
     return cfg;
 }
 
-static constexpr int kMaxDynLds = 160 * 1024;
-
-hipError_t prepare_kernels() {
+// Dynamic LDS above the 64 KiB default must be requested per kernel.  The kernels also hold a
+// few hundred bytes of static LDS (__syncthreads_or), so ask only for what the launch needs.
+hipError_t prepare_kernels(const LaunchCfg &cfg) {
+    if (cfg.lds_bytes <= 64 * 1024) return hipSuccess;
+    const int bytes = (int)cfg.lds_bytes;
     hipError_t e;
 #define EBM_SET(fn) \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxDynLds); \
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
     if (e != hipSuccess) return e;
-    EBM_SET((miz_step_kernel<4, 0>))
-    EBM_SET((miz_step_kernel<4, 1>))
-    EBM_SET((miz_step_kernel<8, 0>))
-    EBM_SET((miz_step_kernel<8, 1>))
-    EBM_SET((classic_step_kernel<4>))
-    EBM_SET((classic_step_kernel<8>))
+    if (cfg.cells == 4) {
+        EBM_SET((miz_step_kernel<4, 0>))
+        EBM_SET((miz_step_kernel<4, 1>))
+        EBM_SET((classic_step_kernel<4>))
+    } else {
+        EBM_SET((miz_step_kernel<8, 0>))
+        EBM_SET((miz_step_kernel<8, 1>))
+        EBM_SET((classic_step_kernel<8>))
+    }
 #undef EBM_SET
     return hipSuccess;
 }

@@ -217,7 +217,7 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
     ebm::LaunchCfg cfg = ebm::choose_launch(nlat);
     if (cfg.threads == 0) return fail(EBM_ERR_UNSUPPORTED, "ebm_create: nlat > 8192 is not supported");
     HIPCHK(hipSetDevice(device));
-    HIPCHK(ebm::prepare_kernels());
+    HIPCHK(ebm::prepare_kernels(cfg));
     ebm_ctx *h = new ebm_ctx();
     h->model = model; h->grid = grid; h->nlat = nlat; h->ncol = ncol; h->device = device;
     h->dt = dt; h->cfg = cfg;

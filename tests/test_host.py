@@ -1,0 +1,128 @@
+"""CPU tests of the host side: the mirror of the reference's operator surface, the column
+sharding logic, and that the C-ABI library loads and exports every symbol that
+include/ebm_hip.h declares (no compute calls — there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "ebm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ebm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(pkg.EXPORTS), declared ^ set(pkg.EXPORTS)
+    assert os.path.exists(pkg.LIB_PATH), "libebm_hip.so missing: run __graft_entry__.build()"
+    lib = ctypes.CDLL(pkg.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.ebm_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.ebm_version()
+
+
+def test_no_gpu_fails_loudly(pkg):
+    """The product has no CPU path: without a GPU ebm_create must fail, never compute."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    st = pkg.SpaceTime("sin", 180, 2000, 1)
+    init = pkg.Collection({k: np.zeros(180) for k in ("Ei", "Ew", "h", "D", "phi")})
+    with pytest.raises(pkg.EBMError, match="no HIP device"):
+        pkg.integrate("MIZ", st, pkg.Forcing(0.0), pkg.default_parameters("MIZ"), init)
+    with pytest.raises(pkg.EBMError, match="no HIP device"):
+        pkg.step_("MIZ", 0.00025, 0.0, init, st, pkg.default_parameters("MIZ"))
+
+
+def test_product_does_not_import_oracle():
+    """The package must not reference oracle/ (the oracle is test infrastructure)."""
+    pdir = os.path.join(ROOT, "energybalancemodel.jl_amd")
+    for dirpath, _, files in os.walk(pdir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "ebm_oracle" not in src and "c_oracle" not in src, f
+                if f.endswith(".py"):
+                    assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+def test_spacetime_matches_oracle_grid(pkg, oracle):
+    for kind in ("sin", "identity"):
+        a, b = pkg.SpaceTime(kind, 180, 2000, 3), oracle.SpaceTime(kind, 180, 2000, 3)
+        assert np.array_equal(a.x, b.x) and np.array_equal(a.t, b.t) and np.array_equal(a.T, b.T)
+        assert (a.winter.inx, a.summer.inx, a.dt) == (b.winter_inx, b.summer_inx, b.dt)
+    assert pkg.SpaceTime("sin", 180, 2000, 1).grid_kind == "nonuniform"
+    assert pkg.SpaceTime("identity", 10, 20, 1).grid_kind == "identity"
+    st = pkg.SpaceTime(lambda u: u * u, 50, 100, 1, urange=(0.0, 1.0))     # custom F
+    assert st.grid_kind == "nonuniform" and st.x[0] == pytest.approx(1e-4)
+    assert repr(pkg.SpaceTime("sin", 180, 2000, 30)) == "SpaceTime{sin}(180, 2000, 30)"
+
+
+def test_forcing_and_parameters(pkg, oracle):
+    f = pkg.Forcing(0.0, 5.0, -5.0, (10, 10), (0.5, -0.5))
+    assert f.domain == (0, 10, 20, 30, 50) and f(17.57) == pytest.approx(3.785, abs=1e-12)
+    g = oracle.Forcing(0.0, 5.0, -5.0, (10, 10), (0.5, -0.5))
+    for T in np.linspace(0, 60, 241):
+        assert f(float(T)) == g(float(T))
+    with pytest.raises(ValueError, match="Warming time"):
+        pkg.Forcing(0.0, 5.0, -5.0, (10, 10), (0.3, -0.5))
+    with pytest.raises(ValueError, match="Cooling time"):
+        pkg.Forcing(0.0, 5.0, -5.0, (10, 10), (0.5, 0.3))
+    assert len(pkg.default_parameters("MIZ")) == 22 and len(pkg.default_parameters("Classic")) == 16
+    assert set(pkg.default_parameters("anything else")) == set(pkg.classic_paramset)
+    p = pkg.default_parameters("MIZ")
+    assert p.Dmax == 156.0 and p.m1 == 1.6e-6 * 31536000
+    p.F = 1.5
+    assert p["F"] == 1.5 and "F" in p.propertynames()
+    with pytest.raises(KeyError):
+        _ = p.nonexistent
+    assert dict(pkg.default_parval) == oracle.default_parval
+
+
+def test_param_vector_order(pkg):
+    from energybalancemodel_jl_amd import _lib, engine
+    hdr = open(os.path.join(ROOT, "include", "ebm_hip.h")).read()
+    enum = re.search(r"enum ebm_param \{(.*?)\}", hdr, flags=re.S).group(1)
+    names = [n.replace("EBM_P_", "") for n in re.findall(r"EBM_P_[A-Za-z0-9]+", enum)]
+    assert tuple(names[:-1]) == _lib.PARAM_ORDER and names[-1] == "COUNT"
+    fld = re.search(r"enum ebm_field \{(.*?)\}", hdr, flags=re.S).group(1)
+    fnames = [n.replace("EBM_F_", "") for n in re.findall(r"EBM_F_[A-Za-z0-9]+", re.sub(r"/\*.*?\*/", "", fld, flags=re.S))]
+    assert fnames[:-1] == sorted(_lib.FIELD, key=_lib.FIELD.get)
+    v = engine.param_vector(pkg.default_parameters("MIZ"), pkg.default_parval)
+    assert v[_lib.PARAM_ORDER.index("F")] == 0.0 and v[_lib.PARAM_ORDER.index("Lf")] == 9.5
+
+
+def test_classic_time_index(pkg, oracle):
+    st = pkg.SpaceTime("identity", 10, 2000, 1)
+    for m in (1, 2, 999, 1000, 1999, 2000):
+        assert pkg.classic_time_index(float(st.t[m - 1]), st.dt, st.nt) == m
+        assert oracle.classic_time_index(float(st.t[m - 1]), st.dt, st.nt) == m
+
+
+def test_model_symbol_and_debug_errors(pkg):
+    st = pkg.SpaceTime("identity", 10, 20, 1)
+    with pytest.raises(ValueError, match="no step! method"):
+        pkg.integrate("classic", st, pkg.Forcing(0.0), pkg.default_parameters("Classic"), {})
+    with pytest.raises(NotImplementedError):
+        pkg.step_("MIZ", 0.1, 0.0, {}, st, pkg.default_parameters("MIZ"), debug="vars.Ei")
+
+
+def test_shard_columns(pkg):
+    for ncol, ws in ((256, 8), (10, 3), (5, 8), (2048, 2)):
+        got = []
+        for r in range(ws):
+            s = pkg.shard_columns(ncol, ws, r)
+            got.extend(range(s.start, s.stop))
+        assert got == list(range(ncol))
+        sizes = [pkg.shard_columns(ncol, ws, r).stop - pkg.shard_columns(ncol, ws, r).start for r in range(ws)]
+        assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        pkg.shard_columns(10, 2, 2)
+
+
+def test_hemispheric_mean(pkg):
+    x = np.linspace(0, 1, 101)
+    assert pkg.hemispheric_mean(2 * x, x) == pytest.approx(1.0, rel=1e-12)   # src/utilities.jl:397-403
