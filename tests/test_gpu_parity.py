@@ -9,6 +9,12 @@ Long trajectories: the reference's own test configuration (sin grid, nx = 180, n
 chaotic — a 1-ulp perturbation of the ORACLE grows to O(1) within the year (DESIGN.md
 "Sensitivity") — so a year-long comparison is only meaningful on the identity grid, where the
 same perturbation stays below 1e-9; there the bar is TOL_YEAR = 1e-7.
+Conditioning: the T0 Jacobian couples neighbours with D/dx^2 ~ 0.25-0.6*nlat^2 against a
+diagonal excess k/h+B ~ 3-22, so cond(J) ~ nlat^2 and ANY backward-stable solve (the oracle's
+Thomas, the reference's dense LU, the GPU's partition + cyclic reduction) carries a forward
+error ~cond*eps: ~1e-13 at nlat=180, ~1e-10 at nlat=1024.  Tolerances for nlat > 256 are
+therefore scaled by (nlat/256)^2 (`size_tol`), and test_t0_solve_accuracy_extended_precision
+checks the GPU's T0 against an 80-bit solve directly.
 NaN sentinels (src/miz.jl:193-194) must coincide exactly.
 """
 import numpy as np
@@ -22,6 +28,10 @@ TOL_STEP, TOL_SHORT, TOL_YEAR = 1e-11, 1e-10, 1e-7
 PROG = ("Ei", "Ew", "h", "D", "phi")
 DIAG = ("Tw", "Ti", "n", "E", "T")
 ALL = PROG + ("T0",) + DIAG
+
+
+def size_tol(tol, nlat):
+    return tol * max(1.0, (nlat / 256.0) ** 2)
 
 
 def make_engine(pkg, model, st, par, ncol=1):
@@ -105,6 +115,64 @@ def test_t0_meets_reference_solver_criterion(pkg, coracle):
         assert np.max(np.abs(res)) < 1e-8, (s, float(np.max(np.abs(res))))
 
 
+@pytest.mark.parametrize("kind,nlat,nt", [("identity", 1024, 131072), ("sin", 4096, 1048576)])
+def test_t0_solve_accuracy_extended_precision(pkg, oracle, coracle, kind, nlat, nt):
+    """The T0 system of one step, solved in 80-bit extended precision on the host (Thomas on
+    the oracle's coefficients, converged active set), is the truth both the GPU and the oracle
+    approximate: the GPU's partition + cyclic-reduction solve must be as accurate as the
+    oracle's fp64 Thomas (same order of magnitude), and both within cond*eps."""
+    st = pkg.SpaceTime(kind, nlat, nt, 1)
+    par = pkg.default_parameters("MIZ")
+    kid = 0 if kind == "identity" else 1
+    state = {k: np.zeros((1, nlat)) for k in PROG + ("T0",)}
+    ct = ctab(pkg, st)
+    spin = 60
+    coracle.miz_run(kid, st.x, dict(par), st.dt, ct[:spin], np.zeros(spin), np.array([1.0]), state)
+    with make_engine(pkg, "MIZ", st, par) as eng:
+        eng.set_state(state)
+        eng.set_column_forcing(np.array([1.0]))
+        eng.set_time_table(st.t)
+        eng.run(spin, 1)
+        T0_gpu = eng.get_field("T0")[0]
+    pre = {k: v.copy() for k, v in state.items()}
+    coracle.miz_run(kid, st.x, dict(par), st.dt, ct[spin:spin + 1], np.zeros(1), np.array([1.0]), state)
+    T0_cpu = state["T0"][0]
+    # assemble the converged linear system exactly as oracle.solve_T0 does, solve it in longdouble
+    p = dict(par)
+    geom = oracle.DiffusionGeometry(kind, st.x, p["D"])
+    h, Ew, phi = pre["h"][0], pre["Ew"][0], pre["phi"][0]
+    with np.errstate(all="ignore"):
+        Tw = oracle.water_temp(Ew, phi, p)
+    Tw = np.where(np.isnan(Tw), 0.0, Tw)
+    hp = np.where(h == 0, p["hmin"], h)
+    L = np.longdouble
+    dd = L(p["k"]) / hp.astype(L) + L(p["B"])
+    r = (1 - phi.astype(L)) * (Tw.astype(L) - L(p["Tm"]))
+    rp = np.concatenate((r[1:], [L(0)])); rm = np.concatenate(([L(0)], r[:-1]))
+    x = st.x.astype(L)
+    S = L(p["S0"]) - L(p["S1"]) * x * L(ct[spin]) - L(p["S2"]) * x * x
+    rhs = L(p["ai"]) * S - L(p["A"]) + (geom.lo * rm + geom.di * r + geom.up * rp) + L(1.0)
+    sset = T0_cpu < p["Tm"]
+    g = np.where(sset, phi, 0.0).astype(L)
+    gp = np.concatenate((g[1:], [L(0)])); gm = np.concatenate(([L(0)], g[:-1]))
+    a, c, b, d = geom.lo * gm, geom.up * gp, geom.di * g - dd, -rhs
+    cp = np.zeros(nlat, L); dp = np.zeros(nlat, L)
+    cp[0] = c[0] / b[0]; dp[0] = d[0] / b[0]
+    for i in range(1, nlat):
+        den = b[i] - a[i] * cp[i - 1]
+        cp[i] = c[i] / den; dp[i] = (d[i] - a[i] * dp[i - 1]) / den
+    v = np.zeros(nlat, L); v[-1] = dp[-1]
+    for i in range(nlat - 2, -1, -1):
+        v[i] = dp[i] - cp[i] * v[i + 1]
+    truth = (v + L(p["Tm"])).astype(np.float64)
+    assert np.array_equal(truth < p["Tm"], sset)
+    e_gpu = float(np.max(np.abs(T0_gpu - truth) / np.maximum(1.0, np.abs(truth))))
+    e_cpu = float(np.max(np.abs(T0_cpu - truth) / np.maximum(1.0, np.abs(truth))))
+    bound = size_tol(1e-12, nlat)
+    assert e_gpu <= bound and e_cpu <= bound, (e_gpu, e_cpu)
+    assert e_gpu <= 20 * e_cpu + 1e-14, (e_gpu, e_cpu)
+
+
 # ---- sizes, raggedness, many columns ----------------------------------------------------------
 @pytest.mark.parametrize("kind,nlat,ncol,nt,spin,nsteps", [
     ("sin", 2, 1, 100, 0, 5),             # smallest legal grid
@@ -139,7 +207,7 @@ def test_miz_sizes_vs_oracle(pkg, coracle, kind, nlat, ncol, nt, spin, nsteps):
     diag, ocnt = coracle.miz_run(kid, st.x, dict(par), st.dt, ct[spin:spin + nsteps], np.zeros(nsteps), fcol, state)
     ref = dict(state)
     ref.update(diag)
-    check_all(got, ref, TOL_SHORT, what=f"{kind} {nlat}x{ncol}")
+    check_all(got, ref, size_tol(TOL_SHORT, nlat), what=f"{kind} {nlat}x{ncol}")
     assert cnt["solves"] == ocnt[0] and cnt["cap_hits"] == 0     # same active-set iteration path
 
 
@@ -259,7 +327,7 @@ def test_classic_sizes_vs_oracle(pkg, coracle, nlat, ncol):
     out = coracle.classic_run(st.x, dict(par), st.dt, ct[idx], ct[(idx + 1) % st.nt], np.zeros(nsteps), fcol, state)
     ref = dict(state)
     ref.update(out)
-    check_all(got, ref, TOL_SHORT, names=("E", "Tg", "T", "h"), what=f"classic {nlat}x{ncol}")
+    check_all(got, ref, size_tol(TOL_SHORT, nlat), names=("E", "Tg", "T", "h"), what=f"classic {nlat}x{ncol}")
 
 
 # ---- the reference's operator surface ------------------------------------------------------------
@@ -353,4 +421,4 @@ def test_full_size_4096x2048_properties(pkg, coracle):
     diag, _ = coracle.miz_run(1, st.x, dict(par), st.dt, ct, np.zeros(nsteps), fcol[sample], state)
     ref = dict(state)
     ref.update(diag)
-    check_all({k: got[k][sample] for k in ALL}, ref, TOL_SHORT, what="4096x2048 sample")
+    check_all({k: got[k][sample] for k in ALL}, ref, size_tol(TOL_SHORT, nlat), what="4096x2048 sample")
