@@ -5,12 +5,14 @@
 
 namespace ebm {
 
-// Parameter block passed to kernels by value.  The first 25 entries mirror default_parval
-// (reference src/infrastructure.jl:407-433); the derived constants are evaluated once on the
-// host in the reference's operation order so that every cell sees the same rounded value.
+// Parameter block, resident in device memory and read through scalar loads.  The first 25
+// entries mirror default_parval (reference src/infrastructure.jl:407-433); the derived
+// constants are evaluated once on the host in the reference's operation order so that every
+// cell sees the same rounded value.
 struct Params {
     double D, A, B, cw, S0, S1, S2, a0, a2, ai, Fb, k, Lf, F, cg, tau, Tm, m1, m2, alpha, rl,
         Dmin, Dmax, hmin, kappa;
+    double dt;          // st.dt
     // MIZ
     double Tm_pow_m2;   // Tm^m2                                   src/miz.jl:71
     double c_latmelt;   // -pi/2.0*alpha                           src/miz.jl:141
@@ -22,41 +24,32 @@ struct Params {
     double cg_tau, dt_tau, dc, M, kLf;
 };
 
-// Per-latitude constant vectors (device pointers, nlat doubles each).
-struct Geometry {
-    const double *x;
-    // physics stencil, bit-exact restatement of the reference's expressions:
-    //   identity grid: g0,g1,g2 = sub, diag, sup of par.D*get_diffop  (infrastructure.jl:480-497)
-    //   other grids:   g0..g4   = mxxph, mxxmh, diffx[i], diffx[i-1], phmmh  (:509-518)
-    const double *g0, *g1, *g2, *g3, *g4;
-    // same operator as plain tridiagonal coefficients; used by the T0 / Tg solves only
-    const double *lo, *di, *up;
-    // classic: kappa's three diagonals, aw, S base (src/classic.jl:21-28)
-    const double *ksub, *kdiag, *ksup, *aw, *Sb;
-};
+// Device state: one slab, field slot s at state + s*fstride, each [ncol][pitch] with
+// pitch = threads*cells >= nlat (latitude contiguous, padding cells kept at zero).
+enum MizSlot { S_Ei = 0, S_Ew, S_h, S_D, S_phi, S_T0, S_Tw, S_Ti, S_n, S_E, S_T, S_MIZ_COUNT };
+enum ClassicSlot { C_E = 0, C_Tg, C_T, C_h, C_COUNT };
 
-struct MizArgs {
-    double *Ei, *Ew, *h, *D, *phi, *T0;   // prognostics + warm start, [ncol][pitch]
-    double *Tw, *Ti, *n, *E, *T;          // diagnostics
-    Geometry g;
-    const double *fcol;                   // per-column forcing offset or nullptr
-    long long pitch;
-    int nlat, ncol;
-    double ct, ft, dt;
-    int write_diag;
-    unsigned long long *counters;         // 64 shards x {solves, cap hits}
-    Params p;
-};
+// Per-latitude constant tables: one slab, table i at geom + i*gstride (gstride = pitch + 4).
+//   G_X              st.x
+//   G_0..G_4         physics stencil, bit-exact restatement of the reference:
+//                      identity grid: sub, diag, sup of par.D*get_diffop  (infrastructure.jl:480-497)
+//                      other grids:   mxxph, mxxmh, diffx[i], diffx[i-1], phmmh  (:509-518)
+//   G_LO, G_DI, G_UP the same operator as plain tridiagonal coefficients (T0 / Tg solves only)
+//   G_KSUB..G_SB     classic: kappa's three diagonals, aw, S base (src/classic.jl:21-28)
+enum GeomTable { G_X = 0, G_0, G_1, G_2, G_3, G_4, G_LO, G_DI, G_UP, G_KSUB, G_KDIAG, G_KSUP, G_AW, G_SB, G_COUNT };
 
-struct ClassicArgs {
-    double *E, *Tg, *T, *h;
-    Geometry g;
-    const double *fcol;
-    long long pitch;
-    int nlat, ncol;
-    double ct_i, ct_ip1, ft, dt;
+struct StepArgs {
+    double *state;
+    long long fstride;
+    const double *geom;
+    long long gstride;
+    const double *fcol;              // per-column forcing offset or nullptr
+    const Params *p;                 // device memory
+    unsigned long long *counters;    // 64 shards x {solves, cap hits} (MIZ)
+    int pitch, nlat, ncol;
+    double ct, ct_next, ft;          // cos(2 pi t) [MIZ / classic column i], classic column i+1, forcing
     int write_diag;
-    Params p;
+    unsigned long long *stamps;      // diagnostic builds only (EBM_STAMPS), else nullptr
 };
 
 struct LaunchCfg {
@@ -68,11 +61,13 @@ struct LaunchCfg {
 constexpr int kCounterShards = 64;
 constexpr int kMaxNewton = 50;
 
-LaunchCfg choose_launch(int nlat);
+LaunchCfg choose_launch(int nlat, bool prefer_c8);
 hipError_t prepare_kernels(const LaunchCfg &cfg);   // raises the dynamic-LDS limit if needed
-hipError_t launch_miz_step(const MizArgs &a, int grid_kind, const LaunchCfg &cfg, hipStream_t s);
-hipError_t launch_classic_step(const ClassicArgs &a, const LaunchCfg &cfg, hipStream_t s);
-// savesol! helpers: dst[i] = src[i] (snapshot) / sum[i] += src[i] / dst[i] = sum[i]/nt; sum[i] = 0
+// MIZ: persistent workgroups, `max_groups` = CUs x resident workgroups per CU
+hipError_t launch_miz_step(const StepArgs &a, int max_groups, int grid_kind, const LaunchCfg &cfg, hipStream_t s);
+int miz_groups_per_cu(const LaunchCfg &cfg);
+hipError_t launch_classic_step(const StepArgs &a, int ncol, const LaunchCfg &cfg, hipStream_t s);
+// savesol! helpers: sum[i] += src[i] ; dst[i] = sum[i]/nt, sum[i] = 0
 hipError_t launch_accumulate(double *sum, const double *src, size_t n, hipStream_t s);
 hipError_t launch_finish_mean(double *dst, double *sum, double nt, size_t n, hipStream_t s);
 

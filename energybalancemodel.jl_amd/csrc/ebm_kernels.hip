@@ -1,28 +1,46 @@
 // HIP kernels (gfx950 / CDNA4, wave64) for the energy-balance time-stepping hot path.
 //
-// One workgroup integrates one meridian (column) for one step.  Everything that the reference
-// does in ~60 temporary vectors per step (src/miz.jl:150-196) is fused into one kernel:
+// One workgroup of T threads integrates one meridian (column) for one step; thread t owns the
+// C contiguous cells t*C .. t*C+C-1 ("chunk ownership") for the whole step.  A lane reads its
+// 8*C contiguous bytes with 16-byte loads, so a wave covers 64*8*C contiguous bytes of the
+// latitude axis per field.  Everything the reference does in ~60 temporary vectors per step
+// (src/miz.jl:150-196) is fused into one kernel:
 //
-//   phase A  coalesced 16-B loads along latitude ("interleaved" ownership: thread t owns the
-//            cell pairs t, t+T, t+2T, ...), water temperature, T0-system right-hand side
-//            (3-point stencil through an LDS tile with implicit zero-flux halo)
-//   phase B  T0 solve: active-set Newton on the piecewise-linear system of src/miz.jl:33-45;
-//            each linear system is tridiagonal and is solved per meridian by a chunk
-//            partition (each thread eliminates its C contiguous rows in registers) followed
-//            by parallel cyclic reduction of the T-row interface system in LDS
-//   phase C  back to interleaved ownership
-//   phase D  Tbar stencil through LDS, radiative + lateral fluxes, enthalpy Euler step,
-//            redistribution, floe size / thickness / concentration update, coalesced stores
+//   phase A  loads; water temperature; right-hand side of the T0 system (3-point stencil: the
+//            chunk interior comes from registers, the two halo cells from the neighbouring
+//            lanes through LDS, zero-flux at equator and pole)
+//   phase B  T0 solve: active-set Newton on the piecewise-linear system of src/miz.jl:33-45.
+//            Each linear system is tridiagonal and is solved per meridian by a chunk
+//            partition (each thread Thomas-eliminates its C rows in registers) followed by
+//            parallel cyclic reduction of the T-row interface system in LDS
+//   phase D  Tbar stencil, radiative + lateral fluxes, enthalpy Euler step, redistribution,
+//            floe size / thickness / concentration update, 16-byte stores
 //
 // Arithmetic policy.  Everything outside the tridiagonal solves is a bit-exact restatement of
 // the reference's expressions (IEEE division, no FMA contraction: build with
 // -ffp-contract=off; the order of operations is the reference's).  The solves are free to use
-// any arithmetic: their result is defined by the linear system, not by an operation order.
+// any arithmetic (explicit FMAs, v_rcp_f64 + Newton): their result is defined by the linear
+// system, not by an operation order.
 //
 // No MFMA: there is no dense contraction on this path; it is HBM-/fp64-VALU-bound.
 #include "ebm_internal.h"
 
 namespace ebm {
+
+// Diagnostic build only (-DEBM_STAMPS): wave 0 of every workgroup records s_memtime at phase
+// boundaries into a.stamps[col*16 + n].  Never enabled in the shipped library.
+#ifdef EBM_STAMPS
+#define EBM_STAMP(n)                                                                   \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        unsigned long long t_;                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 16 + (n)] = t_; \
+    } while (0)
+#else
+#define EBM_STAMP(n) do {} while (0)
+#endif
 
 // ---- Julia IEEE semantics ----------------------------------------------------------------
 __device__ __forceinline__ double jl_min(double x, double y) {
@@ -38,84 +56,57 @@ __device__ __forceinline__ double bool_mul(double x, bool b) {
     return b ? x : __builtin_copysign(0.0, x);   // Bool "strong zero"
 }
 
-// ---- LDS tile addressing -----------------------------------------------------------------
-// A meridian tile holds T*C cells.  One pad element after every C cells makes the stride of
-// a thread's chunk C+1 doubles, which is conflict-free for ds_read_b64 (stride 2(C+1) dwords,
-// C+1 odd) while interleaved (lane-consecutive) accesses stay conflict-free too.
-template <int C>
-__device__ __forceinline__ int pidx(int k) {
-    return k + k / C;
+// ---- solver arithmetic (not order-constrained) ---------------------------------------------
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
 }
 
-// interleaved ownership: thread t holds cell pairs p = t + j*T  (cells 2p, 2p+1)
-template <int C>
-__device__ __forceinline__ void load_il(const double *__restrict__ f, size_t base, int t, int T,
-                                        int plat, double (&v)[C]) {
-#pragma unroll
-    for (int j = 0; j < C / 2; ++j) {
-        int k0 = 2 * (t + j * T);
-        if (k0 < plat) {
-            double2 d = *reinterpret_cast<const double2 *>(f + base + k0);
-            v[2 * j] = d.x;
-            v[2 * j + 1] = d.y;
-        } else {
-            v[2 * j] = 0.0;
-            v[2 * j + 1] = 0.0;
-        }
-    }
+// Identity the optimiser cannot see through: stops it from keeping a value computed in one phase
+// alive across the whole T0 solve just to avoid recomputing it later (register pressure).
+__device__ __forceinline__ double opaque(double x) {
+    asm volatile("" : "+v"(x));
+    return x;
 }
+
+// ---- chunk loads / stores: 8*C contiguous bytes per lane, 16-byte accesses ------------------
+// `f` is a wave-uniform base (kept in SGPRs), `k0` the lane's first cell: the access compiles to
+// the saddr + voffset form, so no per-lane 64-bit pointers are kept alive.
 template <int C>
-__device__ __forceinline__ void store_il(double *__restrict__ f, size_t base, int t, int T,
-                                         int plat, int nlat, const double (&v)[C]) {
+__device__ __forceinline__ void load_chunk(const double *__restrict__ f, unsigned k0, double (&v)[C]) {
 #pragma unroll
     for (int j = 0; j < C / 2; ++j) {
-        int k0 = 2 * (t + j * T);
-        if (k0 < plat) {
-            double2 d;
-            d.x = v[2 * j];
-            d.y = (k0 + 1 < nlat) ? v[2 * j + 1] : 0.0;   // keep the pitch padding at zero
-            *reinterpret_cast<double2 *>(f + base + k0) = d;
-        }
-    }
-}
-// chunk ownership: thread t holds cells t*C .. t*C+C-1 (arrays are padded to T*C on the host)
-template <int C>
-__device__ __forceinline__ void load_chunk(const double *__restrict__ f, int t, double (&v)[C]) {
-#pragma unroll
-    for (int j = 0; j < C / 2; ++j) {
-        double2 d = *reinterpret_cast<const double2 *>(f + t * C + 2 * j);
+        double2 d = *reinterpret_cast<const double2 *>(f + (k0 + 2 * j));
         v[2 * j] = d.x;
         v[2 * j + 1] = d.y;
     }
 }
-// interleaved registers -> LDS tile
 template <int C>
-__device__ __forceinline__ void tile_put_il(double *tile, int t, int T, const double (&v)[C]) {
+__device__ __forceinline__ void store_chunk(double *__restrict__ f, const double (&v)[C], unsigned k0, int nlat) {
 #pragma unroll
     for (int j = 0; j < C / 2; ++j) {
-        int k0 = 2 * (t + j * T);
-        tile[pidx<C>(k0)] = v[2 * j];
-        tile[pidx<C>(k0 + 1)] = v[2 * j + 1];
+        double2 d;
+        d.x = ((int)k0 + 2 * j < nlat) ? v[2 * j] : 0.0;           // padding cells stay zero
+        d.y = ((int)k0 + 2 * j + 1 < nlat) ? v[2 * j + 1] : 0.0;
+        *reinterpret_cast<double2 *>(f + (k0 + 2 * j)) = d;
     }
 }
-template <int C>
-__device__ __forceinline__ void tile_get_il(const double *tile, int t, int T, double (&v)[C]) {
-#pragma unroll
-    for (int j = 0; j < C / 2; ++j) {
-        int k0 = 2 * (t + j * T);
-        v[2 * j] = tile[pidx<C>(k0)];
-        v[2 * j + 1] = tile[pidx<C>(k0 + 1)];
-    }
-}
-template <int C>
-__device__ __forceinline__ void tile_get_chunk(const double *tile, int t, double (&v)[C]) {
-#pragma unroll
-    for (int i = 0; i < C; ++i) v[i] = tile[t * (C + 1) + i];
-}
-template <int C>
-__device__ __forceinline__ void tile_put_chunk(double *tile, int t, const double (&v)[C]) {
-#pragma unroll
-    for (int i = 0; i < C; ++i) tile[t * (C + 1) + i] = v[i];
+
+// Halo exchange: every thread publishes its first and last value; returns the last value of
+// the previous chunk and the first value of the next chunk (0 outside the meridian).
+__device__ __forceinline__ void halo_exchange(double *E0, double *E1, int t, int T, double first,
+                                              double last, double &left, double &right) {
+    E0[t] = first;
+    E1[t] = last;
+    __syncthreads();
+    const int tl = t > 0 ? t - 1 : 0, tr = t + 1 < T ? t + 1 : t;
+    const double l = E1[tl], r = E0[tr];
+    left = t > 0 ? l : 0.0;
+    right = t + 1 < T ? r : 0.0;
 }
 
 // ---- tridiagonal solve of one meridian, T threads x C rows -----------------------------------
@@ -127,76 +118,72 @@ __device__ __forceinline__ void tile_put_chunk(double *tile, int t, const double
 //     tridiagonal system in the T interface values y_t = x_{t*C+C-1}: solve it by parallel
 //     cyclic reduction (normalised rows: one reciprocal per row per level) in LDS.
 //  4. Back-substitute inside the chunk.
-// On entry R0/R1 (>= 3T doubles each) must be free; on exit other threads may still read them.
+// P0/P1: 3T doubles each.  On entry P1 must be free and P0 free after the first barrier inside;
+// on exit other threads may still be reading P0/P1 (callers put a barrier before reuse).
 template <int C>
 __device__ __forceinline__ void partition_solve(const double (&a)[C], const double (&b)[C],
                                                 const double (&c)[C], const double (&d)[C],
-                                                double (&x)[C], int t, int T, double *R0,
-                                                double *R1) {
+                                                double (&x)[C], int t, int T, double *P0,
+                                                double *P1) {
     double cp[C - 1], dp[C - 1], lp[C - 1];
     {
-        double w = 1.0 / b[0];
+        const double w = fast_rcp(b[0]);
         cp[0] = c[0] * w;
         dp[0] = d[0] * w;
         lp[0] = -a[0] * w;
     }
 #pragma unroll
     for (int i = 1; i < C - 1; ++i) {
-        double w = 1.0 / (b[i] - a[i] * cp[i - 1]);
+        const double w = fast_rcp(__builtin_fma(-a[i], cp[i - 1], b[i]));
         cp[i] = c[i] * w;
-        dp[i] = (d[i] - a[i] * dp[i - 1]) * w;
+        dp[i] = __builtin_fma(-a[i], dp[i - 1], d[i]) * w;
         lp[i] = -(a[i] * lp[i - 1]) * w;
     }
     double u = dp[C - 2], v = lp[C - 2], wr = -cp[C - 2];
 #pragma unroll
     for (int i = C - 3; i >= 0; --i) {
-        u = dp[i] - cp[i] * u;
-        v = lp[i] - cp[i] * v;
+        u = __builtin_fma(-cp[i], u, dp[i]);
+        v = __builtin_fma(-cp[i], v, lp[i]);
         wr = -cp[i] * wr;
     }
-    R1[t] = u;
-    R1[T + t] = v;
-    R1[2 * T + t] = wr;
+    P1[t] = u;
+    P1[T + t] = v;
+    P1[2 * T + t] = wr;
     __syncthreads();
-    double un = 0.0, vn = 0.0, wn = 0.0;
-    if (t + 1 < T) {
-        un = R1[t + 1];
-        vn = R1[T + t + 1];
-        wn = R1[2 * T + t + 1];
-    }
+    const bool has_next = t + 1 < T;
+    const int tn = has_next ? t + 1 : t;
+    double un = P1[tn], vn = P1[T + tn], wn = P1[2 * T + tn];
+    un = has_next ? un : 0.0;
+    vn = has_next ? vn : 0.0;
+    wn = has_next ? wn : 0.0;
     double pa, pc, pd;
     {
         const double ae = a[C - 1], be = b[C - 1], ce = c[C - 1], de = d[C - 1];
-        double RA = ae * lp[C - 2];
-        double RB = be - ae * cp[C - 2] + ce * vn;
-        double RC = ce * wn;
-        double RD = de - ae * dp[C - 2] - ce * un;
-        double rinv = 1.0 / RB;
+        const double RA = ae * lp[C - 2];
+        const double RB = __builtin_fma(ce, vn, __builtin_fma(-ae, cp[C - 2], be));
+        const double RC = ce * wn;
+        const double RD = __builtin_fma(-ce, un, __builtin_fma(-ae, dp[C - 2], de));
+        const double rinv = fast_rcp(RB);
         pa = RA * rinv;
         pc = RC * rinv;
         pd = RD * rinv;
     }
-    double *src = R0, *dst = R1;
+    double *src = P0, *dst = P1;
     src[t] = pa;
     src[T + t] = pc;
     src[2 * T + t] = pd;
     __syncthreads();
     for (int s = 1; s < T; s <<= 1) {
-        double am = 0.0, cm = 0.0, dm = 0.0, ap = 0.0, cn = 0.0, dn = 0.0;
-        if (t - s >= 0) {
-            am = src[t - s];
-            cm = src[T + t - s];
-            dm = src[2 * T + t - s];
-        }
-        if (t + s < T) {
-            ap = src[t + s];
-            cn = src[T + t + s];
-            dn = src[2 * T + t + s];
-        }
-        double r = 1.0 / (1.0 - pa * cm - pc * ap);
-        double npd = (pd - pa * dm - pc * dn) * r;
-        double npa = -(pa * am) * r;
-        double npc = -(pc * cn) * r;
+        const bool hm = t - s >= 0, hp = t + s < T;
+        const int im = hm ? t - s : t, ip = hp ? t + s : t;
+        double am = src[im], cm = src[T + im], dm = src[2 * T + im];
+        double ap = src[ip], cn = src[T + ip], dn = src[2 * T + ip];
+        am = hm ? am : 0.0; cm = hm ? cm : 0.0; dm = hm ? dm : 0.0;
+        ap = hp ? ap : 0.0; cn = hp ? cn : 0.0; dn = hp ? dn : 0.0;
+        const double r = fast_rcp(__builtin_fma(-pc, ap, __builtin_fma(-pa, cm, 1.0)));
+        const double npd = __builtin_fma(-pc, dn, __builtin_fma(-pa, dm, pd)) * r;
+        const double npa = -(pa * am) * r;
+        const double npc = -(pc * cn) * r;
         pa = npa;
         pc = npc;
         pd = npd;
@@ -208,10 +195,11 @@ __device__ __forceinline__ void partition_solve(const double (&a)[C], const doub
         src = dst;
         dst = tmp;
     }
-    const double L = t > 0 ? src[2 * T + t - 1] : 0.0;
+    const double Lraw = src[2 * T + (t > 0 ? t - 1 : 0)];
+    const double L = t > 0 ? Lraw : 0.0;
     x[C - 1] = pd;
 #pragma unroll
-    for (int i = C - 2; i >= 0; --i) x[i] = dp[i] + lp[i] * L - cp[i] * x[i + 1];
+    for (int i = C - 2; i >= 0; --i) x[i] = __builtin_fma(-cp[i], x[i + 1], __builtin_fma(lp[i], L, dp[i]));
 }
 
 // ---- MIZ pointwise physics (one cell), bit-exact restatement of src/miz.jl:160-194 ----------
@@ -219,50 +207,51 @@ struct MizCellOut {
     double Ei, Ew, h, D, phi, n, E, T, Ti, Tw;
 };
 
-__device__ __forceinline__ MizCellOut miz_cell_update(const Params &p, double dt, double f,
-                                                     double S, double xk, double dif, double tb,
-                                                     double Ei, double Ew, double hk, double Dk,
-                                                     double ph, double Tw, double Ti) {
-    const double Tm = p.Tm, Lf = p.Lf, alpha = p.alpha;
+__device__ __forceinline__ MizCellOut miz_cell_update(const Params &p, double f, double S, double xk,
+                                                     double dif, double tb, double Ei, double Ew,
+                                                     double hk, double Dk, double ph, double Tw,
+                                                     double Ti) {
+    const double Tm = p.Tm, Lf = p.Lf, alpha = p.alpha, dt = p.dt;
     // num, src/miz.jl:83-87
     double n = ph / (alpha * (Dk * Dk));
     if (Dk == 0.0) n = 0.0;
     // vert_flux, src/miz.jl:96-101 (called twice in the reference with the same Tbar/diffusion)
-    double L = p.A + p.B * (tb - Tm);
-    double sol_i = 0.0 + p.ai * S;
-    double sol_w = 0.0 + (p.a0 - p.a2 * (xk * xk)) * S;
-    double Fvi = sol_i - L + dif + p.Fb + f;
-    double Fvw = sol_w - L + dif + p.Fb + f;
+    const double L = p.A + p.B * (tb - Tm);
+    const double sol_i = 0.0 + p.ai * S;
+    const double sol_w = 0.0 + (p.a0 - p.a2 * (xk * xk)) * S;
+    const double Fvi = sol_i - L + dif + p.Fb + f;
+    const double Fvw = sol_w - L + dif + p.Fb + f;
     // wlat :71, lat_flux :103-107
-    double wl = p.m1 * (Tw - p.Tm_pow_m2);
+    const double wl = p.m1 * (Tw - p.Tm_pow_m2);
     double Flat = ph * hk * Lf * wl * M_PI / (alpha * Dk);
     if (Dk == 0.0) Flat = 0.0;
     // forward Euler (:137-138,148,166-167) and redistributeE (:109-117)
-    double rEi = Ei + (ph * Fvi + Flat) * dt;
-    double rEw = Ew + ((1.0 - ph) * Fvw - Flat) * dt;
-    double cEi = jl_clamp(rEi, -INFINITY, 0.0);
-    double cEw = jl_clamp(rEw, 0.0, INFINITY);
-    double psiEidt = rEi - cEi, psiEwdt = rEw - cEw;
-    double Ei_n = cEi + psiEwdt, Ew_n = cEw + psiEidt;
+    const double rEi = Ei + (ph * Fvi + Flat) * dt;
+    const double rEw = Ew + ((1.0 - ph) * Fvw - Flat) * dt;
+    const double cEi = jl_clamp(rEi, -INFINITY, 0.0);
+    const double cEw = jl_clamp(rEw, 0.0, INFINITY);
+    const double psiEidt = rEi - cEi, psiEwdt = rEw - cEw;
+    double Ei_n = cEi + psiEwdt;
+    const double Ew_n = cEw + psiEidt;
     // area_lead :90-93
-    double Dr = Dk + p.two_rl;
-    double ring = alpha * n * (Dr * Dr - Dk * Dk);
-    double Al = jl_min(ring, 1.0 - ph);
+    const double Dr = Dk + p.two_rl;
+    const double ring = alpha * n * (Dr * Dr - Dk * Dk);
+    const double Al = jl_min(ring, 1.0 - ph);
     // split_psiEw :120-125 applied to psiEwdt/dt (:173)
-    double psi = psiEwdt / dt;
+    const double psi = psiEwdt / dt;
     double Ql = Al / (1.0 - ph) * psi;
     if (ph == 1.0) Ql = 0.0;
-    double Qp = psi - Ql;
+    const double Qp = psi - Ql;
     // psinplus :127, :174
-    double dn = dt * (-Qp / p.c_dn);
+    const double dn = dt * (-Qp / p.c_dn);
     // D_t :140-146
-    double lat_melt = p.c_latmelt * wl;
+    const double lat_melt = p.c_latmelt * wl;
     double lat_grow = -Dk / (2.0 * Lf * hk * ph) * Ql;
-    double weld = p.c_weld * ph * (Dk * Dk * Dk);
+    const double weld = p.c_weld * ph * (Dk * Dk * Dk);
     if (hk == 0.0) lat_grow = 0.0;
-    double rD = Dk + (lat_melt + lat_grow + weld) * dt;
+    const double rD = Dk + (lat_melt + lat_grow + weld) * dt;
     // average :129-134, clamp!, zeroref! (:175-178)
-    double total = n + dn;
+    const double total = n + dn;
     double D_n = (n * rD + dn * p.Dmin) / total;
     if (total == 0.0) D_n = 0.0;
     D_n = jl_clamp(D_n, p.Dmin, p.Dmax);
@@ -299,130 +288,178 @@ __device__ __forceinline__ double diffusion_add(double base, double D, int k, in
                                                 double tbm, double tbk, double tbp) {
     if (GRID == 0) {
         double y = 0.0;
-        if (k > 0) y = y + g0 * tbm;
+        y = (k > 0) ? y + g0 * tbm : y;
         y = y + g1 * tbk;
-        if (k < nlat - 1) y = y + g2 * tbp;
+        y = (k < nlat - 1) ? y + g2 * tbp : y;
         return base + y;
     } else {
-        double dTp = (k < nlat - 1) ? tbp - tbk : 0.0;
-        double dTm = (k > 0) ? tbk - tbm : 0.0;
+        const double dTp = (k < nlat - 1) ? tbp - tbk : 0.0;
+        const double dTm = (k > 0) ? tbk - tbm : 0.0;
         return base + (D * ((g0 * dTp) / g2 - (g1 * dTm) / g3)) / g4;
     }
 }
 
-template <int C, int GRID>
-__global__ void __launch_bounds__(1024) miz_step_kernel(const MizArgs a) {
+// Geometry of the non-uniform stencil from x alone (src/infrastructure.jl:510-518), evaluated
+// with the same IEEE operations, in the same order, as the host-side tables — bit-identical to
+// them, and cheaper than loading five more per-latitude vectors.  xm/xk/xp = x at k-1, k, k+1.
+struct SinGeom {
+    double mph, mmh, dxp, dxm, w;
+};
+__device__ __forceinline__ SinGeom sin_geometry(int k, int nlat, double xm, double xk, double xp) {
+    xm = k > 0 ? xm : -xk;                  // ghost cell [-x[1]; x; 2-x[end]]
+    xp = k < nlat - 1 ? xp : 2.0 - xk;
+    const double xxph = (xp + xk) / 2.0, xxmh = (xk + xm) / 2.0;
+    SinGeom g;
+    g.mph = 1.0 - xxph * xxph;
+    g.mmh = 1.0 - xxmh * xxmh;
+    g.dxp = xp - xk;
+    g.dxm = xk - xm;
+    g.w = xxph - xxmh;
+    return g;
+}
+
+// Tridiagonal coefficients of D d/dx[(1-x^2) d/dx] at cell k of a non-uniform grid
+// (Dif_k(v) = lo (v_{k-1} - v_k) + up (v_{k+1} - v_k)), recomputed from x instead of being loaded:
+// the geometry is bit-identical to the host tables and the remaining arithmetic feeds only the T0
+// solve, which is not order-constrained.  Zero-flux at equator and pole; padding rows inert.
+// (The uniform grid keeps its tables: 1-(k/nx)^2 cancels near the pole and would need IEEE
+// divisions to reproduce the table values.)
+__device__ __forceinline__ void solver_coeffs_nonuniform(const Params &p, int k, int nlat, double xm,
+                                                         double xk, double xp, double &lo, double &up) {
+    const SinGeom g = sin_geometry(k, nlat, xm, xk, xp);
+    const double u = p.D * g.mph * fast_rcp(g.dxp * g.w);
+    const double l = p.D * g.mmh * fast_rcp(g.dxm * g.w);
+    up = (k < nlat - 1) ? u : 0.0;
+    lo = (k > 0 && k < nlat) ? l : 0.0;
+}
+
+// MIZ step: one workgroup per meridian.
+//
+// Geometry (choose_launch): C = 4 cells per thread up to 4096 cells (T <= 1024 threads, <= 128
+// VGPRs), or C = 8 with T <= 512 and up to 256 VGPRs per lane; C = 16 beyond 4096 cells (no LDS
+// stash).  A 4096-cell fp64 meridian fills a CU (512 KiB of VGPRs + 160 KiB of LDS): one
+// workgroup per CU; shorter meridians run several workgroups per CU, which overlap each other.
+//
+// LDS map (doubles; per-cell arrays hold cell i of thread t at i*T + t: lane-consecutive,
+// conflict-free):
+//   P0 = [0,3T), P1 = [3T,6T)    cyclic-reduction ping-pong; idle otherwise, then borrowed for
+//                                the r / g / Tbar halo exchanges
+//   sEw, sh, sTw = [6T, 6T+3CT)  Ew, h, Tw of every cell, parked across the T0 solve so that the
+//                                solve has the register file to itself
+template <int C>
+struct MizCfg {
+    static constexpr bool kStash = C <= 8;
+    static constexpr int kMaxThreads = C >= 8 ? 512 : 1024;
+};
+
+// TT: workgroup size known at compile time (LDS offsets become immediates), 0 = use blockDim.x.
+template <int C, int GRID, bool DIAG, int TT>
+__global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_kernel(const StepArgs a) {
+    constexpr bool STASH = MizCfg<C>::kStash;
     extern __shared__ double smem[];
-    const int T = blockDim.x, t = threadIdx.x, col = blockIdx.x;
-    const int nlat = a.nlat, plat = (int)a.pitch;
-    double *R0 = smem;
-    double *R1 = smem + T * (C + 1);
-    const size_t base = (size_t)col * (size_t)a.pitch;
-    const Params &p = a.p;
+    const int T = TT ? TT : (int)blockDim.x, t = threadIdx.x, col = blockIdx.x;
+    const int nlat = a.nlat;
+    const unsigned k0 = (unsigned)t * C;
+    double *P0 = smem, *P1 = smem + 3 * T;
+    double *sEw = smem + 6 * T + t, *sh = sEw + C * T, *sTw = sh + C * T;
+    const Params &p = *a.p;
+    const double *const gX = a.geom + G_X * a.gstride;
+    double *const st = a.state + (size_t)col * (size_t)a.pitch;         // wave-uniform
     const double f = a.fcol ? a.ft + a.fcol[col] : a.ft;
     const double Tm = p.Tm;
+    EBM_STAMP(0);
 
     // ---------------- phase A: loads, water temperature, T0-system coefficients ----------
-    double Ei[C], Ew[C], hk[C], Dk[C], ph[C], Tw[C], xk[C];
-    load_il<C>(a.Ew, base, t, T, plat, Ew);
-    load_il<C>(a.phi, base, t, T, plat, ph);
-    load_il<C>(a.h, base, t, T, plat, hk);
-    load_il<C>(a.g.x, 0, t, T, plat, xk);
-    double cdd[C], crhs[C], cphi[C], cv0[C];
+    double ph[C], dd[C], r[C], xk[C];
+    double Ewreg[STASH ? 1 : C], hreg[STASH ? 1 : C], Twreg[STASH ? 1 : C];
+    unsigned smask = 0;                                   // active set: bit i <=> T0_i < Tm
+    double xl, xr;
     {
-        double v0[C], lo[C], di[C], up[C], dd[C], r[C], rhs[C], S[C];
-        load_il<C>(a.T0, base, t, T, plat, v0);
-        load_il<C>(a.g.lo, 0, t, T, plat, lo);
-        load_il<C>(a.g.di, 0, t, T, plat, di);
-        load_il<C>(a.g.up, 0, t, T, plat, up);
+        double Ew[C], hk[C], T0w[C];
+        load_chunk<C>(st + S_Ew * a.fstride, k0, Ew);
+        load_chunk<C>(st + S_phi * a.fstride, k0, ph);
+        load_chunk<C>(st + S_h * a.fstride, k0, hk);
+        load_chunk<C>(st + S_T0 * a.fstride, k0, T0w);
+        load_chunk<C>(gX, k0, xk);
+        xl = gX[k0 > 0 ? k0 - 1 : 0];                     // zero-padded table; unused at the ends
+        xr = gX[k0 + C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            const int k = 2 * (t + (c >> 1) * T) + (c & 1);
-            const bool valid = k < nlat;
-            double tw = Tm + Ew[c] / ((1.0 - ph[c]) * p.cw);      // water_temp, src/miz.jl:30
-            tw = __builtin_isnan(tw) ? 0.0 : tw;                  // :157
-            Tw[c] = tw;
-            double hp = (hk[c] == 0.0) ? p.hmin : hk[c];          // :51
-            dd[c] = valid ? p.k / hp + p.B : -1.0;
-            r[c] = valid ? (1.0 - ph[c]) * (tw - Tm) : 0.0;
-            S[c] = p.S0 - p.S1 * xk[c] * a.ct - p.S2 * (xk[c] * xk[c]);   // :11
-            v0[c] = valid ? v0[c] - Tm : 0.0;
-            if (!valid) ph[c] = 0.0;
+        for (int i = 0; i < C; ++i) {
+            const bool valid = (int)k0 + i < nlat;
+            double tw = Tm + Ew[i] / ((1.0 - ph[i]) * p.cw);          // water_temp, src/miz.jl:30
+            tw = __builtin_isnan(tw) ? 0.0 : tw;                      // :157
+            if (STASH) {
+                sEw[i * T] = Ew[i];
+                sh[i * T] = hk[i];
+                sTw[i * T] = tw;
+            } else {
+                Ewreg[STASH ? 0 : i] = Ew[i];
+                hreg[STASH ? 0 : i] = hk[i];
+                Twreg[STASH ? 0 : i] = tw;
+            }
+            const double hp = (hk[i] == 0.0) ? p.hmin : hk[i];        // :51
+            dd[i] = valid ? __builtin_fma(p.k, fast_rcp(hp), p.B) : -1.0;
+            r[i] = valid ? (1.0 - ph[i]) * (tw - Tm) : 0.0;
+            smask |= (valid && T0w[i] < Tm) ? (1u << i) : 0u;         // warm start, :47,52-54
         }
-        tile_put_il<C>(R0, t, T, r);
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < C / 2; ++j) {
-            const int k0 = 2 * (t + j * T);
-            const double rm = k0 > 0 ? R0[pidx<C>(k0 - 1)] : 0.0;
-            const double rp = k0 + 2 < T * C ? R0[pidx<C>(k0 + 2)] : 0.0;
-            const bool v0ok = k0 < nlat, v1ok = k0 + 1 < nlat;
-            rhs[2 * j] = v0ok ? p.ai * S[2 * j] - p.A +
-                                    (lo[2 * j] * rm + di[2 * j] * r[2 * j] + up[2 * j] * r[2 * j + 1]) + f
-                              : 0.0;
-            rhs[2 * j + 1] = v1ok ? p.ai * S[2 * j + 1] - p.A +
-                                        (lo[2 * j + 1] * r[2 * j] + di[2 * j + 1] * r[2 * j + 1] +
-                                         up[2 * j + 1] * rp) + f
-                                  : 0.0;
-        }
-        // interleaved -> chunk ownership, ping-pong between the two tiles (one barrier each)
-        tile_put_il<C>(R1, t, T, dd);
-        __syncthreads();
-        tile_get_chunk<C>(R1, t, cdd);
-        tile_put_il<C>(R0, t, T, rhs);
-        __syncthreads();
-        tile_get_chunk<C>(R0, t, crhs);
-        tile_put_il<C>(R1, t, T, ph);
-        __syncthreads();
-        tile_get_chunk<C>(R1, t, cphi);
-        tile_put_il<C>(R0, t, T, v0);
-        __syncthreads();
-        tile_get_chunk<C>(R0, t, cv0);
     }
+    EBM_STAMP(1);
+    double rl, rr;
+    halo_exchange(P0, P0 + T, t, T, r[0], r[C - 1], rl, rr);
+    EBM_STAMP(2);
 
-    // ---------------- phase B: active-set Newton, src/miz.jl:47-68 ------------------------
+    // ---------------- phase B: active-set Newton, src/miz.jl:33-68 ------------------------
     double xs[C];
     int nit = 0;
     bool ok = false;
-    {
-        double clo[C], cdi[C], cup[C];
-        load_chunk<C>(a.g.lo, t, clo);
-        load_chunk<C>(a.g.di, t, cdi);
-        load_chunk<C>(a.g.up, t, cup);
-        bool s[C];
+    __syncthreads();                                      // r halo reads done before P0 is reused
+    EBM_STAMP(3);
+    while (nit < kMaxNewton) {
+        ++nit;
+        double g[C];
 #pragma unroll
-        for (int i = 0; i < C; ++i) s[i] = cv0[i] < 0.0;
-        __syncthreads();   // tiles free
-        while (nit < kMaxNewton) {
-            ++nit;
-            double g[C];
+        for (int i = 0; i < C; ++i) g[i] = ((smask >> i) & 1u) ? ph[i] : 0.0;
+        double gl, gr;
+        halo_exchange(P0, P0 + T, t, T, g[0], g[C - 1], gl, gr);
+        double ra[C], rb[C], rc[C], rd[C];
+        double tlo[GRID == 0 ? C : 1], tup[GRID == 0 ? C : 1];
+        if constexpr (GRID == 0) {
+            load_chunk<C>(a.geom + G_LO * a.gstride, k0, tlo);
+            load_chunk<C>(a.geom + G_UP * a.gstride, k0, tup);
+        }
 #pragma unroll
-            for (int i = 0; i < C; ++i) g[i] = s[i] ? cphi[i] : 0.0;
-            R0[t] = g[0];
-            R0[T + t] = g[C - 1];
-            __syncthreads();
-            const double gl = t > 0 ? R0[T + t - 1] : 0.0;
-            const double gr = t + 1 < T ? R0[t + 1] : 0.0;
-            double ra[C], rb[C], rc[C], rd[C];
-#pragma unroll
-            for (int i = 0; i < C; ++i) {
-                ra[i] = clo[i] * (i > 0 ? g[i - 1] : gl);
-                rc[i] = cup[i] * (i < C - 1 ? g[i + 1] : gr);
-                rb[i] = cdi[i] * g[i] - cdd[i];
-                rd[i] = -crhs[i];
+        for (int i = 0; i < C; ++i) {
+            const int k = (int)k0 + i;
+            const bool valid = k < nlat;
+            double lo, up;
+            if (GRID == 0) {
+                lo = tlo[GRID == 0 ? i : 0];
+                up = tup[GRID == 0 ? i : 0];
+            } else {
+                solver_coeffs_nonuniform(p, k, nlat, opaque(i > 0 ? xk[i > 0 ? i - 1 : 0] : xl), opaque(xk[i]),
+                                         opaque(i < C - 1 ? xk[i < C - 1 ? i + 1 : i] : xr), lo, up);
             }
-            partition_solve<C>(ra, rb, rc, rd, xs, t, T, R0, R1);
-            int changed = 0;
+            // right-hand side: -(ai S - A + Dif((1-phi)(Tw-Tm)) + f), src/miz.jl:39-43
+            const double S = p.S0 - p.S1 * xk[i] * a.ct - p.S2 * (xk[i] * xk[i]);   // :11
+            const double rm = i > 0 ? r[i > 0 ? i - 1 : 0] : rl;
+            const double rp = i < C - 1 ? r[i < C - 1 ? i + 1 : i] : rr;
+            const double dif = __builtin_fma(up, rp - r[i], lo * (rm - r[i]));
+            rd[i] = valid ? -((p.ai * S - p.A) + dif + f) : 0.0;
+            ra[i] = lo * (i > 0 ? g[i > 0 ? i - 1 : 0] : gl);
+            rc[i] = up * (i < C - 1 ? g[i < C - 1 ? i + 1 : i] : gr);
+            rb[i] = -__builtin_fma(lo + up, g[i], dd[i]);
+        }
+        EBM_STAMP(4);
+        partition_solve<C>(ra, rb, rc, rd, xs, t, T, P0, P1);
+        EBM_STAMP(5);
+        unsigned snew = 0;
 #pragma unroll
-            for (int i = 0; i < C; ++i) {
-                bool sn = xs[i] < 0.0;
-                changed |= (sn != s[i]);
-                s[i] = sn;
-            }
-            if (!__syncthreads_or(changed)) {
-                ok = true;
-                break;
-            }
+        for (int i = 0; i < C; ++i) snew |= (xs[i] < 0.0) ? (1u << i) : 0u;
+        const int changed = snew != smask;
+        smask = snew;
+        if (!__syncthreads_or(changed)) {
+            ok = true;
+            break;
         }
     }
     if (t == 0 && a.counters) {
@@ -430,132 +467,133 @@ __global__ void __launch_bounds__(1024) miz_step_kernel(const MizArgs a) {
         atomicAdd(cnt, (unsigned long long)nit);
         if (!ok) atomicAdd(cnt + 1, 1ull);
     }
-
-    // ---------------- phase C: chunk -> interleaved ownership ---------------------------------
-    double T0[C], Ti[C], tb[C];
-    tile_put_chunk<C>(R0, t, xs);
-    __syncthreads();
-    tile_get_il<C>(R0, t, T, T0);
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        T0[c] = T0[c] + Tm;                                       // new warm start, :64
-        double ti = jl_min(T0[c], Tm);                            // ice_temp, :31,65
-        Ti[c] = (hk[c] == 0.0) ? 0.0 : ti;                        // zeroref!, :66
-        tb[c] = Ti[c] * ph[c] + (1.0 - ph[c]) * Tw[c];            // Tbar, :21-26
-    }
-    store_il<C>(a.T0, base, t, T, plat, nlat, T0);
+    EBM_STAMP(6);
 
     // ---------------- phase D: fluxes and state update ---------------------------------------
-    tile_put_il<C>(R1, t, T, tb);
-    load_il<C>(a.Ei, base, t, T, plat, Ei);
-    load_il<C>(a.D, base, t, T, plat, Dk);
-    double g0[C], g1[C], g2[C], g3[C], g4[C];
-    load_il<C>(a.g.g0, 0, t, T, plat, g0);
-    load_il<C>(a.g.g1, 0, t, T, plat, g1);
-    load_il<C>(a.g.g2, 0, t, T, plat, g2);
-    if (GRID == 1) {
-        load_il<C>(a.g.g3, 0, t, T, plat, g3);
-        load_il<C>(a.g.g4, 0, t, T, plat, g4);
+    double Ei[C], Dk[C];
+    load_chunk<C>(st + S_Ei * a.fstride, k0, Ei);
+    load_chunk<C>(st + S_D * a.fstride, k0, Dk);
+    double g0[GRID == 0 ? C : 1], g1[GRID == 0 ? C : 1], g2[GRID == 0 ? C : 1];
+    if constexpr (GRID == 0) {
+        load_chunk<C>(a.geom + G_0 * a.gstride, k0, g0);
+        load_chunk<C>(a.geom + G_1 * a.gstride, k0, g1);
+        load_chunk<C>(a.geom + G_2 * a.gstride, k0, g2);
     }
-    __syncthreads();
-    double oEi[C], oEw[C], oh[C], oD[C], ophi[C], on[C], oE[C], oT[C], oTi[C], oTw[C];
+    double tb[C];
+    {
+        double T0[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            T0[i] = xs[i] + Tm;                                       // new warm start, :64
+            const double ti = jl_min(T0[i], Tm);                      // ice_temp, :31,65
+            const double hk = STASH ? sh[i * T] : hreg[STASH ? 0 : i];
+            const double tw = STASH ? sTw[i * T] : Twreg[STASH ? 0 : i];
+            xs[i] = (hk == 0.0) ? 0.0 : ti;                           // Ti: zeroref!, :66
+            tb[i] = xs[i] * ph[i] + (1.0 - ph[i]) * tw;               // Tbar, :21-26
+        }
+        store_chunk<C>(st + S_T0 * a.fstride, T0, k0, nlat);
+    }
+    double tbl, tbr;
+    halo_exchange(P0, P0 + T, t, T, tb[0], tb[C - 1], tbl, tbr);
+    EBM_STAMP(7);
 #pragma unroll
     for (int j = 0; j < C / 2; ++j) {
-        const int k0 = 2 * (t + j * T);
-        const double tbm = k0 > 0 ? R1[pidx<C>(k0 - 1)] : 0.0;
-        const double tbp = k0 + 2 < T * C ? R1[pidx<C>(k0 + 2)] : 0.0;
+        MizCellOut o[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int c = 2 * j + q, k = k0 + q;
-            const double m = q == 0 ? tbm : tb[c > 0 ? c - 1 : 0];
-            const double pl = q == 0 ? tb[c + 1 < C ? c + 1 : c] : tbp;
-            const double S = p.S0 - p.S1 * xk[c] * a.ct - p.S2 * (xk[c] * xk[c]);
-            const double dif = diffusion_add<GRID>(0.0, p.D, k, nlat, g0[c], g1[c], g2[c],
-                                                   GRID == 1 ? g3[c] : 0.0, GRID == 1 ? g4[c] : 0.0,
-                                                   m, tb[c], pl);
-            MizCellOut o = miz_cell_update(p, a.dt, f, S, xk[c], dif, tb[c], Ei[c], Ew[c], hk[c],
-                                           Dk[c], ph[c], Tw[c], Ti[c]);
-            oEi[c] = o.Ei; oEw[c] = o.Ew; oh[c] = o.h; oD[c] = o.D; ophi[c] = o.phi;
-            on[c] = o.n; oE[c] = o.E; oT[c] = o.T; oTi[c] = o.Ti; oTw[c] = o.Tw;
+            __builtin_amdgcn_sched_barrier(0);
+            const int i = 2 * j + q, k = (int)k0 + i;
+            const double tbm = i > 0 ? tb[i > 0 ? i - 1 : 0] : tbl;
+            const double tbp = i < C - 1 ? tb[i < C - 1 ? i + 1 : i] : tbr;
+            const double xm = i > 0 ? xk[i > 0 ? i - 1 : 0] : xl;
+            const double xp = i < C - 1 ? xk[i < C - 1 ? i + 1 : i] : xr;
+            const double S = p.S0 - p.S1 * xk[i] * a.ct - p.S2 * (xk[i] * xk[i]);
+            double dif;
+            if (GRID == 0) {
+                dif = diffusion_add<0>(0.0, p.D, k, nlat, g0[GRID == 0 ? i : 0], g1[GRID == 0 ? i : 0],
+                                       g2[GRID == 0 ? i : 0], 0.0, 0.0, tbm, tb[i], tbp);
+            } else {
+                const SinGeom sg = sin_geometry(k, nlat, xm, xk[i], xp);
+                dif = diffusion_add<1>(0.0, p.D, k, nlat, sg.mph, sg.mmh, sg.dxp, sg.dxm, sg.w, tbm, tb[i],
+                                       tbp);
+            }
+            const double Ewk = STASH ? sEw[i * T] : Ewreg[STASH ? 0 : i];
+            const double hk = STASH ? sh[i * T] : hreg[STASH ? 0 : i];
+            const double tw = STASH ? sTw[i * T] : Twreg[STASH ? 0 : i];
+            o[q] = miz_cell_update(p, f, S, xk[i], dif, tb[i], Ei[i], Ewk, hk, Dk[i], ph[i], tw, xs[i]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned kp = k0 + 2 * j;
+        const bool v0 = (int)kp < nlat, v1 = (int)kp + 1 < nlat;
+#define EBM_PUT(slot, member)                                                                  \
+        {                                                                                          \
+            double2 d_;                                                                            \
+            d_.x = v0 ? o[0].member : 0.0;                                                         \
+            d_.y = v1 ? o[1].member : 0.0;                                                         \
+            *reinterpret_cast<double2 *>(st + (slot) * a.fstride + kp) = d_;                       \
+        }
+        EBM_PUT(S_Ei, Ei) EBM_PUT(S_Ew, Ew) EBM_PUT(S_h, h) EBM_PUT(S_D, D) EBM_PUT(S_phi, phi)
+        if (DIAG) {
+            EBM_PUT(S_n, n) EBM_PUT(S_E, E) EBM_PUT(S_T, T) EBM_PUT(S_Ti, Ti) EBM_PUT(S_Tw, Tw)
+        }
+#undef EBM_PUT
+        if (j < 2) EBM_STAMP(8 + j);
     }
-    store_il<C>(a.Ei, base, t, T, plat, nlat, oEi);
-    store_il<C>(a.Ew, base, t, T, plat, nlat, oEw);
-    store_il<C>(a.h, base, t, T, plat, nlat, oh);
-    store_il<C>(a.D, base, t, T, plat, nlat, oD);
-    store_il<C>(a.phi, base, t, T, plat, nlat, ophi);
-    if (a.write_diag) {
-        store_il<C>(a.n, base, t, T, plat, nlat, on);
-        store_il<C>(a.E, base, t, T, plat, nlat, oE);
-        store_il<C>(a.T, base, t, T, plat, nlat, oT);
-        store_il<C>(a.Ti, base, t, T, plat, nlat, oTi);
-        store_il<C>(a.Tw, base, t, T, plat, nlat, oTw);
-    }
+    EBM_STAMP(15);
 }
 
 // ---- classic (WE15) step, src/classic.jl:37-71 ------------------------------------------------
 template <int C>
-__global__ void __launch_bounds__(1024) classic_step_kernel(const ClassicArgs a) {
+__global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) classic_step_kernel(const StepArgs a) {
     extern __shared__ double smem[];
     const int T = blockDim.x, t = threadIdx.x, col = blockIdx.x;
-    const int nlat = a.nlat, plat = (int)a.pitch;
-    double *R0 = smem;
-    double *R1 = smem + T * (C + 1);
-    const size_t base = (size_t)col * (size_t)a.pitch;
-    const Params &p = a.p;
+    const int nlat = a.nlat;
+    const unsigned k0 = (unsigned)t * C;
+    double *P0 = smem, *P1 = smem + 3 * T;
+    const Params &p = *a.p;
+    double *const st = a.state + (size_t)col * (size_t)a.pitch;          // wave-uniform
+    const double *const ge = a.geom;
     const double f = a.fcol ? a.ft + a.fcol[col] : a.ft;
 
     double E[C], Tg[C], xk[C], aw[C], Sb[C], kd[C];
-    load_il<C>(a.E, base, t, T, plat, E);
-    load_il<C>(a.Tg, base, t, T, plat, Tg);
-    load_il<C>(a.g.x, 0, t, T, plat, xk);
-    load_il<C>(a.g.aw, 0, t, T, plat, aw);
-    load_il<C>(a.g.Sb, 0, t, T, plat, Sb);
-    load_il<C>(a.g.kdiag, 0, t, T, plat, kd);
+    load_chunk<C>(st + C_E * a.fstride, k0, E);
+    load_chunk<C>(st + C_Tg * a.fstride, k0, Tg);
+    load_chunk<C>(ge + G_X * a.gstride, k0, xk);
+    load_chunk<C>(ge + G_AW * a.gstride, k0, aw);
+    load_chunk<C>(ge + G_SB * a.gstride, k0, Sb);
+    load_chunk<C>(ge + G_KDIAG * a.gstride, k0, kd);
     double b[C], d[C], oT[C], oh[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        const int k = 2 * (t + (c >> 1) * T) + (c & 1);
-        const bool valid = k < nlat;
-        double Ek = E[c];
-        const double S_i = Sb[c] - (p.S1 * a.ct_i) * xk[c];                        // :23-24
-        const double S_ip1 = Sb[c] - (p.S1 * a.ct_ip1) * xk[c];
-        const double alpha = bool_mul(aw[c], Ek > 0.0) + bool_mul(p.ai, Ek < 0.0); // :47
-        const double Cc = alpha * S_i + p.cg_tau * Tg[c] - p.A + f;                // :48
+    for (int i = 0; i < C; ++i) {
+        const bool valid = (int)k0 + i < nlat;
+        double Ek = E[i];
+        const double S_i = Sb[i] - (p.S1 * a.ct) * xk[i];                          // :23-24
+        const double S_ip1 = Sb[i] - (p.S1 * a.ct_next) * xk[i];
+        const double alpha = bool_mul(aw[i], Ek > 0.0) + bool_mul(p.ai, Ek < 0.0); // :47
+        const double Cc = alpha * S_i + p.cg_tau * Tg[i] - p.A + f;                // :48
         const double T0 = Cc / (p.M - p.kLf / Ek);                                 // :50
         const double Tk = bool_mul(Ek / p.cw, Ek >= 0.0) + bool_mul(bool_mul(T0, Ek < 0.0), T0 < 0.0);
-        Ek = Ek + a.dt * (Cc - p.M * Tk + p.Fb);                                   // :53
+        Ek = Ek + p.dt * (Cc - p.M * Tk + p.Fb);                                   // :53
         const double den = p.M - p.kLf / Ek;
         const double q = bool_mul(bool_mul(p.dc / den, T0 < 0.0), Ek < 0.0);       // :56
-        const double rhs = Tg[c] + p.dt_tau * (bool_mul(Ek / p.cw, Ek >= 0.0) +
+        const double rhs = Tg[i] + p.dt_tau * (bool_mul(Ek / p.cw, Ek >= 0.0) +
                            bool_mul(bool_mul((p.ai * S_ip1 - p.A + f) / den, T0 < 0.0), Ek < 0.0));
-        b[c] = valid ? kd[c] - q : 1.0;
-        d[c] = valid ? rhs : 0.0;
-        E[c] = Ek;
-        oT[c] = Tk;
-        oh[c] = bool_mul(-Ek / p.Lf, Ek < 0.0);                                    // :65
+        b[i] = valid ? kd[i] - q : 1.0;
+        d[i] = valid ? rhs : 0.0;
+        E[i] = Ek;
+        oT[i] = Tk;
+        oh[i] = bool_mul(-Ek / p.Lf, Ek < 0.0);                                    // :65
     }
-    store_il<C>(a.E, base, t, T, plat, nlat, E);
+    store_chunk<C>(st + C_E * a.fstride, E, k0, nlat);
     if (a.write_diag) {
-        store_il<C>(a.T, base, t, T, plat, nlat, oT);
-        store_il<C>(a.h, base, t, T, plat, nlat, oh);
+        store_chunk<C>(st + C_T * a.fstride, oT, k0, nlat);
+        store_chunk<C>(st + C_h * a.fstride, oh, k0, nlat);
     }
-    double cb[C], cd[C], ca[C], cc[C], xs[C];
-    tile_put_il<C>(R0, t, T, b);
-    __syncthreads();
-    tile_get_chunk<C>(R0, t, cb);
-    tile_put_il<C>(R1, t, T, d);
-    __syncthreads();
-    tile_get_chunk<C>(R1, t, cd);
-    load_chunk<C>(a.g.ksub, t, ca);
-    load_chunk<C>(a.g.ksup, t, cc);
-    __syncthreads();
-    partition_solve<C>(ca, cb, cc, cd, xs, t, T, R0, R1);   // Implicit Euler for Tg, :55-63
-    __syncthreads();
-    tile_put_chunk<C>(R0, t, xs);
-    __syncthreads();
-    tile_get_il<C>(R0, t, T, Tg);
-    store_il<C>(a.Tg, base, t, T, plat, nlat, Tg);
+    double ca[C], cc[C], xs[C];
+    load_chunk<C>(ge + G_KSUB * a.gstride, k0, ca);
+    load_chunk<C>(ge + G_KSUP * a.gstride, k0, cc);
+    partition_solve<C>(ca, b, cc, d, xs, t, T, P0, P1);   // Implicit Euler for Tg, :55-63
+    store_chunk<C>(st + C_Tg * a.fstride, xs, k0, nlat);
 }
 
 // ---- savesol! helpers (src/infrastructure.jl:549-591, src/utilities.jl:390-395) ---------------
@@ -571,60 +609,98 @@ __global__ void finish_mean_kernel(double *__restrict__ dst, double *__restrict_
 }
 
 // ---- host-side launchers ----------------------------------------------------------------------
-LaunchCfg choose_launch(int nlat) {
+// prefer_c8: use 8 cells per thread (512 threads, 256 VGPRs) already for 2048 < nlat <= 4096.
+LaunchCfg choose_launch(int nlat, bool prefer_c8) {
     LaunchCfg cfg{};
-    for (int C : {4, 8}) {
-        int chunks = (nlat + C - 1) / C;
-        int T = ((chunks + 63) / 64) * 64;
-        if (T <= 1024) {
-            cfg.threads = T;
-            cfg.cells = C;
-            cfg.lds_bytes = sizeof(double) * 2 * (size_t)T * (C + 1);
-            return cfg;
-        }
+    int C = nlat <= 4096 ? 4 : (nlat <= 8192 ? 16 : 0);
+    if (prefer_c8 && nlat > 2048 && nlat <= 4096) C = 8;
+    if (C == 0) {
+        cfg.threads = 0;       // nlat > 8192
+        return cfg;
     }
-    cfg.threads = 0;
+    const int chunks = (nlat + C - 1) / C;
+    cfg.threads = ((chunks + 63) / 64) * 64;
+    cfg.cells = C;
+    // 2 x 3T cyclic reduction; MIZ with C <= 8 also parks Ew, h, Tw (3 C T)
+    cfg.lds_bytes = sizeof(double) * (size_t)cfg.threads * (6 + (C <= 8 ? 3 * (size_t)C : 0));
     return cfg;
 }
 
-// Dynamic LDS above the 64 KiB default must be requested per kernel.  The kernels also hold a
-// few hundred bytes of static LDS (__syncthreads_or), so ask only for what the launch needs.
-hipError_t prepare_kernels(const LaunchCfg &cfg) {
-    if (cfg.lds_bytes <= 64 * 1024) return hipSuccess;
-    const int bytes = (int)cfg.lds_bytes;
+// All instantiations of the MIZ kernel for one C: grid kind x diagnostics x {generic T, fixed T}.
+template <int C, int TT, typename F>
+static hipError_t for_each_miz(F &&fn) {
     hipError_t e;
-#define EBM_SET(fn) \
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
-    if (e != hipSuccess) return e;
-    if (cfg.cells == 4) {
-        EBM_SET((miz_step_kernel<4, 0>))
-        EBM_SET((miz_step_kernel<4, 1>))
-        EBM_SET((classic_step_kernel<4>))
-    } else {
-        EBM_SET((miz_step_kernel<8, 0>))
-        EBM_SET((miz_step_kernel<8, 1>))
-        EBM_SET((classic_step_kernel<8>))
-    }
-#undef EBM_SET
+    if ((e = fn(reinterpret_cast<const void *>(miz_step_kernel<C, 0, false, TT>))) != hipSuccess) return e;
+    if ((e = fn(reinterpret_cast<const void *>(miz_step_kernel<C, 1, false, TT>))) != hipSuccess) return e;
+    if ((e = fn(reinterpret_cast<const void *>(miz_step_kernel<C, 0, true, TT>))) != hipSuccess) return e;
+    if ((e = fn(reinterpret_cast<const void *>(miz_step_kernel<C, 1, true, TT>))) != hipSuccess) return e;
     return hipSuccess;
 }
 
-hipError_t launch_miz_step(const MizArgs &a, int grid_kind, const LaunchCfg &cfg, hipStream_t s) {
-    dim3 grid(a.ncol), block(cfg.threads);
+// Dynamic LDS above the 64 KiB default must be requested per kernel.
+hipError_t prepare_kernels(const LaunchCfg &cfg) {
+    if (cfg.lds_bytes <= 64 * 1024) return hipSuccess;
+    const int bytes = (int)cfg.lds_bytes;
+    auto set = [bytes](const void *fn) {
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    };
+    hipError_t e = hipSuccess;
     if (cfg.cells == 4) {
-        if (grid_kind == 0) miz_step_kernel<4, 0><<<grid, block, cfg.lds_bytes, s>>>(a);
-        else miz_step_kernel<4, 1><<<grid, block, cfg.lds_bytes, s>>>(a);
+        if ((e = for_each_miz<4, 0>(set)) != hipSuccess) return e;
+        if ((e = for_each_miz<4, 1024>(set)) != hipSuccess) return e;
+        e = set(reinterpret_cast<const void *>(classic_step_kernel<4>));
+    } else if (cfg.cells == 8) {
+        if ((e = for_each_miz<8, 0>(set)) != hipSuccess) return e;
+        if ((e = for_each_miz<8, 512>(set)) != hipSuccess) return e;
+        e = set(reinterpret_cast<const void *>(classic_step_kernel<8>));
     } else {
-        if (grid_kind == 0) miz_step_kernel<8, 0><<<grid, block, cfg.lds_bytes, s>>>(a);
-        else miz_step_kernel<8, 1><<<grid, block, cfg.lds_bytes, s>>>(a);
+        if ((e = for_each_miz<16, 0>(set)) != hipSuccess) return e;
+        e = set(reinterpret_cast<const void *>(classic_step_kernel<16>));
+    }
+    return e;
+}
+
+template <int C, int TT>
+static void launch_miz_ct(const StepArgs &a, dim3 grid, dim3 block, int grid_kind, size_t lds, hipStream_t s) {
+    if (grid_kind == 0) {
+        if (a.write_diag) miz_step_kernel<C, 0, true, TT><<<grid, block, lds, s>>>(a);
+        else miz_step_kernel<C, 0, false, TT><<<grid, block, lds, s>>>(a);
+    } else {
+        if (a.write_diag) miz_step_kernel<C, 1, true, TT><<<grid, block, lds, s>>>(a);
+        else miz_step_kernel<C, 1, false, TT><<<grid, block, lds, s>>>(a);
+    }
+}
+
+// Resident workgroups per CU: C = 4 uses <= 128 VGPRs per lane (16 waves per CU), C >= 8 up to 256
+// (8 waves per CU); 160 KiB of LDS.
+int miz_groups_per_cu(const LaunchCfg &cfg) {
+    int by_waves = (cfg.cells >= 8 ? 512 : 1024) / cfg.threads;
+    int by_lds = (int)((160 * 1024 - 512) / cfg.lds_bytes);
+    int g = by_waves < by_lds ? by_waves : by_lds;
+    return g < 1 ? 1 : g;
+}
+
+hipError_t launch_miz_step(const StepArgs &a, int max_groups, int grid_kind, const LaunchCfg &cfg, hipStream_t s) {
+    (void)max_groups;
+    dim3 grid(a.ncol), block(cfg.threads);
+    const size_t lds = cfg.lds_bytes;
+    if (cfg.cells == 4) {
+        if (cfg.threads == 1024) launch_miz_ct<4, 1024>(a, grid, block, grid_kind, lds, s);
+        else launch_miz_ct<4, 0>(a, grid, block, grid_kind, lds, s);
+    } else if (cfg.cells == 8) {
+        if (cfg.threads == 512) launch_miz_ct<8, 512>(a, grid, block, grid_kind, lds, s);
+        else launch_miz_ct<8, 0>(a, grid, block, grid_kind, lds, s);
+    } else {
+        launch_miz_ct<16, 0>(a, grid, block, grid_kind, lds, s);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_classic_step(const ClassicArgs &a, const LaunchCfg &cfg, hipStream_t s) {
-    dim3 grid(a.ncol), block(cfg.threads);
+hipError_t launch_classic_step(const StepArgs &a, int ncol, const LaunchCfg &cfg, hipStream_t s) {
+    dim3 grid(ncol), block(cfg.threads);
     if (cfg.cells == 4) classic_step_kernel<4><<<grid, block, cfg.lds_bytes, s>>>(a);
-    else classic_step_kernel<8><<<grid, block, cfg.lds_bytes, s>>>(a);
+    else if (cfg.cells == 8) classic_step_kernel<8><<<grid, block, cfg.lds_bytes, s>>>(a);
+    else classic_step_kernel<16><<<grid, block, cfg.lds_bytes, s>>>(a);
     return hipGetLastError();
 }
 

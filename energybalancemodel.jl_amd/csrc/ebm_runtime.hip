@@ -2,8 +2,10 @@
 // constant tables, the step / run / integrate drivers and HIP-event timing.  Device work is in
 // ebm_kernels.hip.  There is deliberately no CPU fallback: without a GPU every entry point
 // fails with EBM_ERR_NO_DEVICE.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,11 +35,17 @@ struct ebm_ctx {
     long long pitch = 0;
     double dt = 0.0;
     ebm::Params p{};
-    ebm::Geometry g{};
     ebm::LaunchCfg cfg{};
-    std::vector<double *> dev_tables;              // owned device allocations (geometry)
-    double *field[EBM_F_COUNT] = {nullptr};
+    ebm::Params *p_dev = nullptr;                  // parameter block in device memory
+    double *geom = nullptr;                        // per-latitude tables, G_COUNT x gstride
+    long long gstride = 0;
+    double *state = nullptr;                       // field slab, nslots x fstride
+    long long fstride = 0;
+    int nslots = 0;
+    double *field[EBM_F_COUNT] = {nullptr};        // views into the slab (null: not in this model)
     double *fcol = nullptr;
+    unsigned long long *stamps = nullptr;          // diagnostic builds only
+    int num_cus = 0;
     std::vector<double> ttab;                      // cos(2*pi*t_i), host copy
     unsigned long long *counters = nullptr;        // device, kCounterShards x 2
     long long n_steps = 0, n_launches = 0;
@@ -47,29 +55,24 @@ struct ebm_ctx {
 
 namespace {
 
-bool has_field(const ebm_ctx *h, int f) {
-    if (h->model == EBM_MODEL_MIZ) return f >= EBM_F_Ei && f <= EBM_F_T;
-    return f == EBM_F_E || f == EBM_F_Tg || f == EBM_F_T || f == EBM_F_h;
+// slab slot of a public field id for this model, -1 if the model does not have it
+int slot_of(int model, int f) {
+    if (model == EBM_MODEL_MIZ) return (f >= EBM_F_Ei && f <= EBM_F_T) ? f : -1;   // same order
+    switch (f) {
+        case EBM_F_E: return ebm::C_E;
+        case EBM_F_Tg: return ebm::C_Tg;
+        case EBM_F_T: return ebm::C_T;
+        case EBM_F_h: return ebm::C_h;
+        default: return -1;
+    }
 }
-
-// Upload a per-latitude table padded with zeros to `padded` entries.
-int upload_table(ebm_ctx *h, const std::vector<double> &v, size_t padded, const double **out) {
-    std::vector<double> tmp(padded, 0.0);
-    std::memcpy(tmp.data(), v.data(), sizeof(double) * v.size());
-    double *d = nullptr;
-    HIPCHK(hipMalloc(&d, sizeof(double) * padded));
-    h->dev_tables.push_back(d);
-    HIPCHK(hipMemcpy(d, tmp.data(), sizeof(double) * padded, hipMemcpyHostToDevice));
-    *out = d;
-    return EBM_OK;
-}
+bool has_field(const ebm_ctx *h, int f) { return f >= 0 && f < EBM_F_COUNT && slot_of(h->model, f) >= 0; }
 
 // Per-latitude constants.  Same expressions, in the same order, as the reference:
 // get_diffop (src/infrastructure.jl:480-492), the non-uniform cache (:509-518) and
 // get_statics (src/classic.jl:18-29).
 int build_tables(ebm_ctx *h, const double *x) {
     const int nx = h->nlat;
-    const size_t padded = (size_t)h->cfg.threads * h->cfg.cells + 2;
     const ebm::Params &p = h->p;
     std::vector<double> xv(x, x + nx), g0(nx), g1(nx), g2(nx), g3(nx, 0.0), g4(nx, 0.0), lo(nx), di(nx), up(nx);
     const bool uniform = (h->grid == EBM_GRID_IDENTITY) || (h->model == EBM_MODEL_CLASSIC);
@@ -115,16 +118,14 @@ int build_tables(ebm_ctx *h, const double *x) {
             di[k] = -(l + u);
         }
     }
-    int rc;
-    if ((rc = upload_table(h, xv, padded, &h->g.x))) return rc;
-    if ((rc = upload_table(h, g0, padded, &h->g.g0))) return rc;
-    if ((rc = upload_table(h, g1, padded, &h->g.g1))) return rc;
-    if ((rc = upload_table(h, g2, padded, &h->g.g2))) return rc;
-    if ((rc = upload_table(h, g3, padded, &h->g.g3))) return rc;
-    if ((rc = upload_table(h, g4, padded, &h->g.g4))) return rc;
-    if ((rc = upload_table(h, lo, padded, &h->g.lo))) return rc;
-    if ((rc = upload_table(h, di, padded, &h->g.di))) return rc;
-    if ((rc = upload_table(h, up, padded, &h->g.up))) return rc;
+    // one zero-padded slab: table i at geom + i*gstride
+    h->gstride = h->pitch;
+    std::vector<double> slab((size_t)ebm::G_COUNT * h->gstride, 0.0);
+    auto put = [&](int table, const std::vector<double> &v) {
+        std::memcpy(slab.data() + (size_t)table * h->gstride, v.data(), sizeof(double) * v.size());
+    };
+    put(ebm::G_X, xv); put(ebm::G_0, g0); put(ebm::G_1, g1); put(ebm::G_2, g2); put(ebm::G_3, g3);
+    put(ebm::G_4, g4); put(ebm::G_LO, lo); put(ebm::G_DI, di); put(ebm::G_UP, up);
     if (h->model == EBM_MODEL_CLASSIC) {
         std::vector<double> ksub(nx), kdiag(nx), ksup(nx), aw(nx), Sb(nx);
         const double dtD = h->dt * p.D;
@@ -136,12 +137,11 @@ int build_tables(ebm_ctx *h, const double *x) {
             aw[k] = p.a0 - p.a2 * (x[k] * x[k]);
             Sb[k] = p.S0 - p.S2 * (x[k] * x[k]);
         }
-        if ((rc = upload_table(h, ksub, padded, &h->g.ksub))) return rc;
-        if ((rc = upload_table(h, kdiag, padded, &h->g.kdiag))) return rc;
-        if ((rc = upload_table(h, ksup, padded, &h->g.ksup))) return rc;
-        if ((rc = upload_table(h, aw, padded, &h->g.aw))) return rc;
-        if ((rc = upload_table(h, Sb, padded, &h->g.Sb))) return rc;
+        put(ebm::G_KSUB, ksub); put(ebm::G_KDIAG, kdiag); put(ebm::G_KSUP, ksup);
+        put(ebm::G_AW, aw); put(ebm::G_SB, Sb);
     }
+    HIPCHK(hipMalloc(&h->geom, sizeof(double) * slab.size()));
+    HIPCHK(hipMemcpy(h->geom, slab.data(), sizeof(double) * slab.size(), hipMemcpyHostToDevice));
     return EBM_OK;
 }
 
@@ -153,6 +153,7 @@ void fill_params(ebm::Params &p, const double *v, double dt) {
     p.Tm = v[EBM_P_Tm]; p.m1 = v[EBM_P_m1]; p.m2 = v[EBM_P_m2]; p.alpha = v[EBM_P_alpha];
     p.rl = v[EBM_P_rl]; p.Dmin = v[EBM_P_Dmin]; p.Dmax = v[EBM_P_Dmax]; p.hmin = v[EBM_P_hmin];
     p.kappa = v[EBM_P_kappa];
+    p.dt = dt;
     p.Tm_pow_m2 = std::pow(p.Tm, p.m2);
     p.c_latmelt = -M_PI / 2.0 * p.alpha;
     p.c_dn = p.Lf * p.alpha * (p.Dmin * p.Dmin) * p.hmin;
@@ -167,26 +168,15 @@ void fill_params(ebm::Params &p, const double *v, double dt) {
 }
 
 int do_step(ebm_ctx *h, double ct, double ct_next, double f, int write_diag) {
-    hipError_t e;
-    if (h->model == EBM_MODEL_MIZ) {
-        ebm::MizArgs a{};
-        a.Ei = h->field[EBM_F_Ei]; a.Ew = h->field[EBM_F_Ew]; a.h = h->field[EBM_F_h];
-        a.D = h->field[EBM_F_D]; a.phi = h->field[EBM_F_phi]; a.T0 = h->field[EBM_F_T0];
-        a.Tw = h->field[EBM_F_Tw]; a.Ti = h->field[EBM_F_Ti]; a.n = h->field[EBM_F_n];
-        a.E = h->field[EBM_F_E]; a.T = h->field[EBM_F_T];
-        a.g = h->g; a.fcol = h->fcol; a.pitch = h->pitch; a.nlat = h->nlat; a.ncol = h->ncol;
-        a.ct = ct; a.ft = f; a.dt = h->dt; a.write_diag = write_diag;
-        a.counters = h->counters; a.p = h->p;
-        e = ebm::launch_miz_step(a, h->grid, h->cfg, h->stream);
-    } else {
-        ebm::ClassicArgs a{};
-        a.E = h->field[EBM_F_E]; a.Tg = h->field[EBM_F_Tg]; a.T = h->field[EBM_F_T];
-        a.h = h->field[EBM_F_h];
-        a.g = h->g; a.fcol = h->fcol; a.pitch = h->pitch; a.nlat = h->nlat; a.ncol = h->ncol;
-        a.ct_i = ct; a.ct_ip1 = ct_next; a.ft = f; a.dt = h->dt; a.write_diag = write_diag;
-        a.p = h->p;
-        e = ebm::launch_classic_step(a, h->cfg, h->stream);
-    }
+    ebm::StepArgs a{};
+    a.state = h->state; a.fstride = h->fstride; a.geom = h->geom; a.gstride = h->gstride;
+    a.fcol = h->fcol; a.p = h->p_dev; a.counters = h->counters;
+    a.pitch = (int)h->pitch; a.nlat = h->nlat; a.ncol = h->ncol;
+    a.ct = ct; a.ct_next = ct_next; a.ft = f; a.write_diag = write_diag;
+    a.stamps = h->stamps;
+    hipError_t e = (h->model == EBM_MODEL_MIZ)
+                       ? ebm::launch_miz_step(a, h->num_cus * ebm::miz_groups_per_cu(h->cfg), h->grid, h->cfg, h->stream)
+                       : ebm::launch_classic_step(a, h->ncol, h->cfg, h->stream);
     if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     h->n_steps += 1;
     h->n_launches += 1;
@@ -214,25 +204,36 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(EBM_ERR_NO_DEVICE, "ebm_create: no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(EBM_ERR_ARG, "ebm_create: device index out of range");
-    ebm::LaunchCfg cfg = ebm::choose_launch(nlat);
+    const char *geo = std::getenv("EBM_CELLS_PER_THREAD");   // tuning knob: "8" = 512 threads x 8 cells for long meridians
+    ebm::LaunchCfg cfg = ebm::choose_launch(nlat, geo && std::atoi(geo) == 8);
     if (cfg.threads == 0) return fail(EBM_ERR_UNSUPPORTED, "ebm_create: nlat > 8192 is not supported");
     HIPCHK(hipSetDevice(device));
     HIPCHK(ebm::prepare_kernels(cfg));
     ebm_ctx *h = new ebm_ctx();
     h->model = model; h->grid = grid; h->nlat = nlat; h->ncol = ncol; h->device = device;
     h->dt = dt; h->cfg = cfg;
-    h->pitch = (nlat + 1) / 2 * 2;
+    {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        h->num_cus = prop.multiProcessorCount;
+    }
+    h->pitch = (long long)cfg.threads * cfg.cells;     // >= nlat; padding cells stay zero
     fill_params(h->p, params, dt);
     int rc = build_tables(h, x);
     if (rc) { ebm_destroy(h); return rc; }
-    const size_t nbytes = sizeof(double) * (size_t)ncol * (size_t)h->pitch;
+    h->fstride = (long long)ncol * h->pitch;
+    h->nslots = (model == EBM_MODEL_MIZ) ? (int)ebm::S_MIZ_COUNT : (int)ebm::C_COUNT;
+    const size_t nbytes = sizeof(double) * (size_t)h->nslots * (size_t)h->fstride;
+    hipError_t e = hipMalloc(&h->state, nbytes);
+    if (e == hipSuccess) e = hipMemset(h->state, 0, nbytes);
+    if (e == hipSuccess) e = hipMalloc(&h->p_dev, sizeof(ebm::Params));
+    if (e == hipSuccess) e = hipMemcpy(h->p_dev, &h->p, sizeof(ebm::Params), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { ebm_destroy(h); return fail(EBM_ERR_HIP, std::string("state allocation: ") + hipGetErrorString(e)); }
     for (int f = 0; f < EBM_F_COUNT; ++f) {
-        if (!has_field(h, f)) continue;
-        hipError_t e = hipMalloc(&h->field[f], nbytes);
-        if (e == hipSuccess) e = hipMemset(h->field[f], 0, nbytes);
-        if (e != hipSuccess) { ebm_destroy(h); return fail(EBM_ERR_HIP, std::string("field allocation: ") + hipGetErrorString(e)); }
+        const int slot = slot_of(model, f);
+        h->field[f] = slot >= 0 ? h->state + (size_t)slot * h->fstride : nullptr;
     }
-    hipError_t e = hipMalloc(&h->counters, sizeof(unsigned long long) * 2 * ebm::kCounterShards);
+    e = hipMalloc(&h->counters, sizeof(unsigned long long) * 2 * ebm::kCounterShards);
     if (e == hipSuccess) e = hipMemset(h->counters, 0, sizeof(unsigned long long) * 2 * ebm::kCounterShards);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
@@ -246,9 +247,9 @@ int ebm_destroy(ebm_handle_t h) {
     if (!h) return EBM_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (double *d : h->dev_tables) (void)hipFree(d);
-    for (int f = 0; f < EBM_F_COUNT; ++f)
-        if (h->field[f]) (void)hipFree(h->field[f]);
+    if (h->geom) (void)hipFree(h->geom);
+    if (h->state) (void)hipFree(h->state);
+    if (h->p_dev) (void)hipFree(h->p_dev);
     if (h->fcol) (void)hipFree(h->fcol);
     if (h->counters) (void)hipFree(h->counters);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -260,7 +261,7 @@ int ebm_destroy(ebm_handle_t h) {
 
 int ebm_set_field(ebm_handle_t h, int field, const double *host) {
     if (!h || !host) return fail(EBM_ERR_ARG, "ebm_set_field: null argument");
-    if (field < 0 || field >= EBM_F_COUNT || !has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_set_field: field not part of this model");
+    if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_set_field: field not part of this model");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy2D(h->field[field], sizeof(double) * h->pitch, host, sizeof(double) * h->nlat,
@@ -270,7 +271,7 @@ int ebm_set_field(ebm_handle_t h, int field, const double *host) {
 
 int ebm_get_field(ebm_handle_t h, int field, double *host) {
     if (!h || !host) return fail(EBM_ERR_ARG, "ebm_get_field: null argument");
-    if (field < 0 || field >= EBM_F_COUNT || !has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_get_field: field not part of this model");
+    if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_get_field: field not part of this model");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy2D(host, sizeof(double) * h->nlat, h->field[field], sizeof(double) * h->pitch,
@@ -280,7 +281,7 @@ int ebm_get_field(ebm_handle_t h, int field, double *host) {
 
 int ebm_field_device_ptr(ebm_handle_t h, int field, double **dptr, long long *pitch) {
     if (!h || !dptr) return fail(EBM_ERR_ARG, "ebm_field_device_ptr: null argument");
-    if (field < 0 || field >= EBM_F_COUNT || !has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_field_device_ptr: field not part of this model");
+    if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_field_device_ptr: field not part of this model");
     *dptr = h->field[field];
     if (pitch) *pitch = h->pitch;
     return EBM_OK;
@@ -332,7 +333,7 @@ int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int la
     if (!h || nt < 1 || dur < 1 || nvars < 0 || (nvars > 0 && !fields)) return fail(EBM_ERR_ARG, "ebm_integrate: bad argument");
     if ((long long)h->ttab.size() != nt) return fail(EBM_ERR_ARG, "ebm_integrate: time table length must equal nt");
     for (int v = 0; v < nvars; ++v)
-        if (fields[v] < 0 || fields[v] >= EBM_F_COUNT || !has_field(h, fields[v])) return fail(EBM_ERR_ARG, "ebm_integrate: field not part of this model");
+        if (!has_field(h, fields[v])) return fail(EBM_ERR_ARG, "ebm_integrate: field not part of this model");
     HIPCHK(hipSetDevice(h->device));
     const size_t ncell = (size_t)h->ncol * h->nlat;          // packed cells per snapshot
     const size_t npitch = (size_t)h->ncol * h->pitch;        // device elements per field
@@ -476,6 +477,23 @@ int ebm_timer_stop(ebm_handle_t h, float *elapsed_ms) {
     HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
     return EBM_OK;
 }
+
+#ifdef EBM_STAMPS
+// Diagnostic build only: allocate / fetch the per-workgroup phase stamps (ncol x 16).
+int ebm_debug_stamps(ebm_handle_t h, unsigned long long *host) {
+    if (!h) return fail(EBM_ERR_ARG, "ebm_debug_stamps: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t nb = sizeof(unsigned long long) * 16 * (size_t)h->ncol;
+    if (!h->stamps) {
+        HIPCHK(hipMalloc(&h->stamps, nb));
+        HIPCHK(hipMemset(h->stamps, 0, nb));
+        return EBM_OK;
+    }
+    if (host) HIPCHK(hipMemcpy(host, h->stamps, nb, hipMemcpyDeviceToHost));
+    return EBM_OK;
+}
+#endif
 
 int ebm_launch_info(ebm_handle_t h, int *info) {
     if (!h || !info) return fail(EBM_ERR_ARG, "ebm_launch_info: null argument");

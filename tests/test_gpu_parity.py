@@ -181,7 +181,7 @@ def test_t0_solve_accuracy_extended_precision(pkg, oracle, coracle, kind, nlat, 
     ("identity", 257, 2, 8000, 10, 30),
     ("sin", 1000, 5, 60000, 20, 20),      # 256 threads, ragged
     ("sin", 1440, 2, 131072, 50, 20),     # BASELINE configs[1]: 1-D MIZ, 1440 bands
-    ("identity", 1024, 8, 131072, 50, 20),
+    ("identity", 1024, 8, 262144, 50, 20),  # nt: 2x the explicit stability limit cw dx^2/(2D)
     ("sin", 4096, 6, 1048576, 50, 10),    # BASELINE configs[3] meridian length, 1024 threads
     ("sin", 4100, 2, 1048576, 20, 5),     # > 4096: 8 cells per thread
     ("sin", 8192, 1, 4194304, 10, 3),     # maximum supported meridian length
