@@ -50,18 +50,24 @@ def cpu_baseline(pkg, wl, st, par, state, fcol, first_step, budget_s):
     cores = co.max_threads()
     model, kind, nlat, ncol, nt = wl
     kid = 0 if kind == "identity" else 1
-    ct = np.array([pkg.cos2pit(float(t)) for t in st.t[first_step % nt:(first_step % nt) + 64]])
-    ncols = min(ncol, max(cores * 4, 16))
+    ncols = min(ncol, max(cores * 8, 64))
     sub = {k: np.ascontiguousarray(v[:ncols]) for k, v in state.items()}
     fc = None if fcol is None else np.ascontiguousarray(fcol[:ncols])
-    # probe, then size the sample to the budget
+    i0 = first_step % nt
+
+    def table(n):
+        return np.array([pkg.cos2pit(float(st.t[(i0 + i) % nt])) for i in range(n)])
+
+    # probe (after a one-step warm-up of the thread pool), then size the sample to the budget
+    co.miz_run(kid, st.x, dict(par), st.dt, table(1), np.zeros(1), fc, sub, nthreads=cores)
     probe = 4
     t0 = time.perf_counter()
-    co.miz_run(kid, st.x, dict(par), st.dt, ct[:probe], np.zeros(probe), fc, sub, nthreads=cores)
+    co.miz_run(kid, st.x, dict(par), st.dt, table(probe), np.zeros(probe), fc, sub, nthreads=cores)
     rate = ncols * nlat * probe / (time.perf_counter() - t0)
-    nsteps = int(max(8, min(60, budget_s * rate / (ncols * nlat))))
+    nsteps = int(max(8, min(20000, budget_s * rate / (ncols * nlat))))
+    ct = table(nsteps)
     t0 = time.perf_counter()
-    co.miz_run(kid, st.x, dict(par), st.dt, ct[:nsteps], np.zeros(nsteps), fc, sub, nthreads=cores)
+    co.miz_run(kid, st.x, dict(par), st.dt, ct, np.zeros(nsteps), fc, sub, nthreads=cores)
     dt = time.perf_counter() - t0
     return {
         "value": ncols * nlat * nsteps / dt, "unit": "grid-cell-steps/s", "cores": cores,

@@ -46,6 +46,7 @@ struct StepArgs {
     const double *fcol;              // per-column forcing offset or nullptr
     const Params *p;                 // device memory
     unsigned long long *counters;    // 64 shards x {solves, cap hits} (MIZ)
+    unsigned short *amask;           // MIZ warm start as an active set: [ncol][threads], bit i <=> T0 < Tm in cell i of the thread
     int pitch, nlat, ncol;
     double ct, ct_next, ft;          // cos(2 pi t) [MIZ / classic column i], classic column i+1, forcing
     int write_diag;
@@ -68,6 +69,8 @@ hipError_t launch_miz_step(const StepArgs &a, int max_groups, int grid_kind, con
 int miz_groups_per_cu(const LaunchCfg &cfg);
 hipError_t launch_classic_step(const StepArgs &a, int ncol, const LaunchCfg &cfg, hipStream_t s);
 // savesol! helpers: sum[i] += src[i] ; dst[i] = sum[i]/nt, sum[i] = 0
+// active set from the T0 field (after ebm_set_field(T0))
+hipError_t launch_mask_from_t0(const StepArgs &a, int ncol, const LaunchCfg &cfg, hipStream_t s);
 hipError_t launch_accumulate(double *sum, const double *src, size_t n, hipStream_t s);
 hipError_t launch_finish_mean(double *dst, double *sum, double nt, size_t n, hipStream_t s);
 

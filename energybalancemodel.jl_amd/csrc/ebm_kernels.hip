@@ -372,14 +372,17 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
     // ---------------- phase A: loads, water temperature, T0-system coefficients ----------
     double ph[C], dd[C], r[C], xk[C];
     double Ewreg[STASH ? 1 : C], hreg[STASH ? 1 : C], Twreg[STASH ? 1 : C];
-    unsigned smask = 0;                                   // active set: bit i <=> T0_i < Tm
     double xl, xr;
+    // Warm start (src/miz.jl:47,52-54,64).  The reference carries T0 itself between steps; the
+    // active-set iteration only uses its sign pattern, so between steps the library carries that
+    // pattern (one bit per cell) and writes the fp64 T0 field on diagnostic launches only.
+    unsigned short *const wmask = a.amask + (size_t)col * T + t;
+    unsigned smask = *wmask;                              // active set: bit i <=> T0_i < Tm
     {
-        double Ew[C], hk[C], T0w[C];
+        double Ew[C], hk[C];
         load_chunk<C>(st + S_Ew * a.fstride, k0, Ew);
         load_chunk<C>(st + S_phi * a.fstride, k0, ph);
         load_chunk<C>(st + S_h * a.fstride, k0, hk);
-        load_chunk<C>(st + S_T0 * a.fstride, k0, T0w);
         load_chunk<C>(gX, k0, xk);
         xl = gX[k0 > 0 ? k0 - 1 : 0];                     // zero-padded table; unused at the ends
         xr = gX[k0 + C];
@@ -400,7 +403,6 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
             const double hp = (hk[i] == 0.0) ? p.hmin : hk[i];        // :51
             dd[i] = valid ? __builtin_fma(p.k, fast_rcp(hp), p.B) : -1.0;
             r[i] = valid ? (1.0 - ph[i]) * (tw - Tm) : 0.0;
-            smask |= (valid && T0w[i] < Tm) ? (1u << i) : 0u;         // warm start, :47,52-54
         }
     }
     EBM_STAMP(1);
@@ -467,12 +469,10 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
         atomicAdd(cnt, (unsigned long long)nit);
         if (!ok) atomicAdd(cnt + 1, 1ull);
     }
+    *wmask = (unsigned short)smask;                       // new warm start, src/miz.jl:64
     EBM_STAMP(6);
 
     // ---------------- phase D: fluxes and state update ---------------------------------------
-    double Ei[C], Dk[C];
-    load_chunk<C>(st + S_Ei * a.fstride, k0, Ei);
-    load_chunk<C>(st + S_D * a.fstride, k0, Dk);
     double g0[GRID == 0 ? C : 1], g1[GRID == 0 ? C : 1], g2[GRID == 0 ? C : 1];
     if constexpr (GRID == 0) {
         load_chunk<C>(a.geom + G_0 * a.gstride, k0, g0);
@@ -491,14 +491,24 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
             xs[i] = (hk == 0.0) ? 0.0 : ti;                           // Ti: zeroref!, :66
             tb[i] = xs[i] * ph[i] + (1.0 - ph[i]) * tw;               // Tbar, :21-26
         }
-        store_chunk<C>(st + S_T0 * a.fstride, T0, k0, nlat);
+        if (DIAG) store_chunk<C>(st + S_T0 * a.fstride, T0, k0, nlat);
     }
     double tbl, tbr;
     halo_exchange(P0, P0 + T, t, T, tb[0], tb[C - 1], tbl, tbr);
     EBM_STAMP(7);
+    // Whole-line stores.  A lane owns 8*C contiguous bytes of every field; written pair by pair,
+    // each 128-B line would reach L2 in two halves ~10^4 cycles apart and be written back to HBM
+    // twice.  For C = 4 the first pair's new prognostics are parked in LDS words that are dead by
+    // then (cells 0,1 of the stash, the idle tail of the cyclic-reduction buffers) and all 32 bytes
+    // of a lane go out in two back-to-back 16-B stores once the second pair is done.
+    constexpr bool WHOLE = STASH && C == 4;
+    double *const park0 = P0 + 2 * T + t;                 // P0[2T..3T), P1[0..3T): clear of the halo words
 #pragma unroll
     for (int j = 0; j < C / 2; ++j) {
         MizCellOut o[2];
+        __builtin_amdgcn_sched_barrier(0);
+        const double2 Ei2 = *reinterpret_cast<const double2 *>(st + S_Ei * a.fstride + (k0 + 2 * j));
+        const double2 Dk2 = *reinterpret_cast<const double2 *>(st + S_D * a.fstride + (k0 + 2 * j));
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             __builtin_amdgcn_sched_barrier(0);
@@ -520,7 +530,8 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
             const double Ewk = STASH ? sEw[i * T] : Ewreg[STASH ? 0 : i];
             const double hk = STASH ? sh[i * T] : hreg[STASH ? 0 : i];
             const double tw = STASH ? sTw[i * T] : Twreg[STASH ? 0 : i];
-            o[q] = miz_cell_update(p, f, S, xk[i], dif, tb[i], Ei[i], Ewk, hk, Dk[i], ph[i], tw, xs[i]);
+            o[q] = miz_cell_update(p, f, S, xk[i], dif, tb[i], q ? Ei2.y : Ei2.x, Ewk, hk, q ? Dk2.y : Dk2.x,
+                                   ph[i], tw, xs[i]);
         }
         __builtin_amdgcn_sched_barrier(0);
         const unsigned kp = k0 + 2 * j;
@@ -532,7 +543,33 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
             d_.y = v1 ? o[1].member : 0.0;                                                         \
             *reinterpret_cast<double2 *>(st + (slot) * a.fstride + kp) = d_;                       \
         }
-        EBM_PUT(S_Ei, Ei) EBM_PUT(S_Ew, Ew) EBM_PUT(S_h, h) EBM_PUT(S_D, D) EBM_PUT(S_phi, phi)
+        if (WHOLE && j == 0) {
+            // pair 0 of Ei, Ew -> P words; h, D, phi -> stash words of cells 0, 1 (all read already)
+            park0[0] = v0 ? o[0].Ei : 0.0;  park0[T] = v1 ? o[1].Ei : 0.0;
+            park0[2 * T] = v0 ? o[0].Ew : 0.0;  park0[3 * T] = v1 ? o[1].Ew : 0.0;
+            sEw[0] = v0 ? o[0].h : 0.0;  sEw[T] = v1 ? o[1].h : 0.0;
+            sh[0] = v0 ? o[0].D : 0.0;  sh[T] = v1 ? o[1].D : 0.0;
+            sTw[0] = v0 ? o[0].phi : 0.0;  sTw[T] = v1 ? o[1].phi : 0.0;
+        } else if (WHOLE) {
+#define EBM_PUT4(slot, member, w0, w1)                                                             \
+            {                                                                                      \
+                double2 a_, b_;                                                                    \
+                a_.x = (w0);                                                                       \
+                a_.y = (w1);                                                                       \
+                b_.x = v0 ? o[0].member : 0.0;                                                     \
+                b_.y = v1 ? o[1].member : 0.0;                                                     \
+                *reinterpret_cast<double2 *>(st + (slot) * a.fstride + k0) = a_;                   \
+                *reinterpret_cast<double2 *>(st + (slot) * a.fstride + kp) = b_;                   \
+            }
+            EBM_PUT4(S_Ei, Ei, park0[0], park0[T])
+            EBM_PUT4(S_Ew, Ew, park0[2 * T], park0[3 * T])
+            EBM_PUT4(S_h, h, sEw[0], sEw[T])
+            EBM_PUT4(S_D, D, sh[0], sh[T])
+            EBM_PUT4(S_phi, phi, sTw[0], sTw[T])
+#undef EBM_PUT4
+        } else {
+            EBM_PUT(S_Ei, Ei) EBM_PUT(S_Ew, Ew) EBM_PUT(S_h, h) EBM_PUT(S_D, D) EBM_PUT(S_phi, phi)
+        }
         if (DIAG) {
             EBM_PUT(S_n, n) EBM_PUT(S_E, E) EBM_PUT(S_T, T) EBM_PUT(S_Ti, Ti) EBM_PUT(S_Tw, Tw)
         }
@@ -594,6 +631,17 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) classic_step_kernel(co
     load_chunk<C>(ge + G_KSUP * a.gstride, k0, cc);
     partition_solve<C>(ca, b, cc, d, xs, t, T, P0, P1);   // Implicit Euler for Tg, :55-63
     store_chunk<C>(st + C_Tg * a.fstride, xs, k0, nlat);
+}
+
+// Active set of a T0 field (after ebm_set_field(T0)): bit i of amask[col][t] <=> T0 < Tm in cell t*C+i.
+__global__ void mask_from_t0_kernel(const StepArgs a, int C) {
+    const int T = blockDim.x, t = threadIdx.x, col = blockIdx.x;
+    const double Tm = a.p->Tm;
+    const double *T0 = a.state + S_T0 * a.fstride + (size_t)col * (size_t)a.pitch + (size_t)t * C;
+    unsigned m = 0;
+    for (int i = 0; i < C; ++i)
+        if (t * C + i < a.nlat && T0[i] < Tm) m |= 1u << i;
+    a.amask[(size_t)col * T + t] = (unsigned short)m;
 }
 
 // ---- savesol! helpers (src/infrastructure.jl:549-591, src/utilities.jl:390-395) ---------------
@@ -701,6 +749,11 @@ hipError_t launch_classic_step(const StepArgs &a, int ncol, const LaunchCfg &cfg
     if (cfg.cells == 4) classic_step_kernel<4><<<grid, block, cfg.lds_bytes, s>>>(a);
     else if (cfg.cells == 8) classic_step_kernel<8><<<grid, block, cfg.lds_bytes, s>>>(a);
     else classic_step_kernel<16><<<grid, block, cfg.lds_bytes, s>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mask_from_t0(const StepArgs &a, int ncol, const LaunchCfg &cfg, hipStream_t s) {
+    mask_from_t0_kernel<<<ncol, cfg.threads, 0, s>>>(a, cfg.cells);
     return hipGetLastError();
 }
 

@@ -48,6 +48,7 @@ struct ebm_ctx {
     int num_cus = 0;
     std::vector<double> ttab;                      // cos(2*pi*t_i), host copy
     unsigned long long *counters = nullptr;        // device, kCounterShards x 2
+    unsigned short *amask = nullptr;               // MIZ warm-start active set, ncol x threads
     long long n_steps = 0, n_launches = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -167,8 +168,17 @@ void fill_params(ebm::Params &p, const double *v, double dt) {
     p.kLf = p.k * p.Lf;
 }
 
-int do_step(ebm_ctx *h, double ct, double ct_next, double f, int write_diag) {
+ebm::StepArgs base_args(const ebm_ctx *h) {
     ebm::StepArgs a{};
+    a.state = h->state; a.fstride = h->fstride; a.geom = h->geom; a.gstride = h->gstride;
+    a.fcol = h->fcol; a.p = h->p_dev; a.counters = h->counters; a.amask = h->amask;
+    a.pitch = (int)h->pitch; a.nlat = h->nlat; a.ncol = h->ncol;
+    a.stamps = h->stamps;
+    return a;
+}
+
+int do_step(ebm_ctx *h, double ct, double ct_next, double f, int write_diag) {
+    ebm::StepArgs a = base_args(h);
     a.state = h->state; a.fstride = h->fstride; a.geom = h->geom; a.gstride = h->gstride;
     a.fcol = h->fcol; a.p = h->p_dev; a.counters = h->counters;
     a.pitch = (int)h->pitch; a.nlat = h->nlat; a.ncol = h->ncol;
@@ -226,6 +236,11 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
     const size_t nbytes = sizeof(double) * (size_t)h->nslots * (size_t)h->fstride;
     hipError_t e = hipMalloc(&h->state, nbytes);
     if (e == hipSuccess) e = hipMemset(h->state, 0, nbytes);
+    if (e == hipSuccess && model == EBM_MODEL_MIZ) {
+        const size_t mb = sizeof(unsigned short) * (size_t)ncol * cfg.threads;
+        e = hipMalloc(&h->amask, mb);
+        if (e == hipSuccess) e = hipMemset(h->amask, 0, mb);
+    }
     if (e == hipSuccess) e = hipMalloc(&h->p_dev, sizeof(ebm::Params));
     if (e == hipSuccess) e = hipMemcpy(h->p_dev, &h->p, sizeof(ebm::Params), hipMemcpyHostToDevice);
     if (e != hipSuccess) { ebm_destroy(h); return fail(EBM_ERR_HIP, std::string("state allocation: ") + hipGetErrorString(e)); }
@@ -250,6 +265,7 @@ int ebm_destroy(ebm_handle_t h) {
     if (h->geom) (void)hipFree(h->geom);
     if (h->state) (void)hipFree(h->state);
     if (h->p_dev) (void)hipFree(h->p_dev);
+    if (h->amask) (void)hipFree(h->amask);
     if (h->fcol) (void)hipFree(h->fcol);
     if (h->counters) (void)hipFree(h->counters);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -266,6 +282,12 @@ int ebm_set_field(ebm_handle_t h, int field, const double *host) {
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy2D(h->field[field], sizeof(double) * h->pitch, host, sizeof(double) * h->nlat,
                        sizeof(double) * h->nlat, h->ncol, hipMemcpyHostToDevice));
+    if (field == EBM_F_T0 && h->model == EBM_MODEL_MIZ) {
+        // the stepping kernels carry the warm start as its active set: rebuild it from the new T0
+        hipError_t e = ebm::launch_mask_from_t0(base_args(h), h->ncol, h->cfg, h->stream);
+        if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("mask_from_t0: ") + hipGetErrorString(e));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     return EBM_OK;
 }
 

@@ -22,14 +22,13 @@ eng.run(300, 3, None, False); eng.sync()
 nwg = eng.launch_info()["workgroups"]
 buf = np.zeros((ncol, 16), dtype=np.uint64)
 lib.ebm_debug_stamps(eng._h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)))
-s = buf.astype(np.int64)[:nwg]   # persistent kernel: stamps of the LAST meridian of each workgroup
+s = buf.astype(np.int64)[:nwg]
 names = ["start", "A:loads+Tw", "A:r halo", "A:rhs+sync", "B:g halo+rows", "B:partition solve", "B:check+sync",
          "D:tb+halo", "D:pair0", "D:pair1", "-", "-", "-", "-", "-", "end"]
-order = [1, 2, 3, 4, 5, 6, 7, 8, 9, 15]
+order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15]
 d = np.diff(s[:, order], axis=1)
-tot = (s[:, 15] - s[:, 0]) / max(1, ncol // nwg)   # per meridian (persistent kernel: 0 is the kernel start)
+tot = (s[:, 15] - s[:, 0])
 print("median total cycles per workgroup (s_memtime ticks):", np.median(tot))
-print("  (phase A of an iteration = total minus the phases below)")
 for i, k in enumerate(order[1:]):
     print(f"  {names[k]:22s} median {np.median(d[:, i]):9.0f}  ({100*np.median(d[:, i])/np.median(tot):5.1f} %)")
 t0 = s[:, 0] - s[:, 0].min()
