@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libebm_hip.so")
+# EBM_LIB: alternative build of the same library (A/B benchmarking of kernel variants)
+LIB_PATH = os.environ.get("EBM_LIB") or os.path.join(_HERE, "libebm_hip.so")
 
 # enum ebm_model / ebm_grid / ebm_field / ebm_param (include/ebm_hip.h)
 MODEL = {"MIZ": 0, "Classic": 1}

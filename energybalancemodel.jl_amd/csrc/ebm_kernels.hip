@@ -173,13 +173,13 @@ __device__ __forceinline__ void partition_solve(const double (&a)[C], const doub
     src[T + t] = pc;
     src[2 * T + t] = pd;
     __syncthreads();
+    // Out-of-range neighbours need no special case: by induction pa == 0 exactly whenever row
+    // t-s does not exist (and pc == 0 when t+s does not), so reading a clamped, finite row and
+    // multiplying by that zero contributes nothing.
     for (int s = 1; s < T; s <<= 1) {
-        const bool hm = t - s >= 0, hp = t + s < T;
-        const int im = hm ? t - s : t, ip = hp ? t + s : t;
-        double am = src[im], cm = src[T + im], dm = src[2 * T + im];
-        double ap = src[ip], cn = src[T + ip], dn = src[2 * T + ip];
-        am = hm ? am : 0.0; cm = hm ? cm : 0.0; dm = hm ? dm : 0.0;
-        ap = hp ? ap : 0.0; cn = hp ? cn : 0.0; dn = hp ? dn : 0.0;
+        const int im = t - s >= 0 ? t - s : t, ip = t + s < T ? t + s : t;
+        const double am = src[im], cm = src[T + im], dm = src[2 * T + im];
+        const double ap = src[ip], cn = src[T + ip], dn = src[2 * T + ip];
         const double r = fast_rcp(__builtin_fma(-pc, ap, __builtin_fma(-pa, cm, 1.0)));
         const double npd = __builtin_fma(-pc, dn, __builtin_fma(-pa, dm, pd)) * r;
         const double npa = -(pa * am) * r;
@@ -318,21 +318,6 @@ __device__ __forceinline__ SinGeom sin_geometry(int k, int nlat, double xm, doub
     return g;
 }
 
-// Tridiagonal coefficients of D d/dx[(1-x^2) d/dx] at cell k of a non-uniform grid
-// (Dif_k(v) = lo (v_{k-1} - v_k) + up (v_{k+1} - v_k)), recomputed from x instead of being loaded:
-// the geometry is bit-identical to the host tables and the remaining arithmetic feeds only the T0
-// solve, which is not order-constrained.  Zero-flux at equator and pole; padding rows inert.
-// (The uniform grid keeps its tables: 1-(k/nx)^2 cancels near the pole and would need IEEE
-// divisions to reproduce the table values.)
-__device__ __forceinline__ void solver_coeffs_nonuniform(const Params &p, int k, int nlat, double xm,
-                                                         double xk, double xp, double &lo, double &up) {
-    const SinGeom g = sin_geometry(k, nlat, xm, xk, xp);
-    const double u = p.D * g.mph * fast_rcp(g.dxp * g.w);
-    const double l = p.D * g.mmh * fast_rcp(g.dxm * g.w);
-    up = (k < nlat - 1) ? u : 0.0;
-    lo = (k > 0 && k < nlat) ? l : 0.0;
-}
-
 // MIZ step: one workgroup per meridian.
 //
 // Geometry (choose_launch): C = 4 cells per thread up to 4096 cells (T <= 1024 threads, <= 128
@@ -370,7 +355,7 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
     EBM_STAMP(0);
 
     // ---------------- phase A: loads, water temperature, T0-system coefficients ----------
-    double ph[C], dd[C], r[C], xk[C];
+    double ph[C], dd[C], r[C], xk[C], tlo[C], tup[C];         // tlo/tup: tridiagonal coefficients of D lap
     double Ewreg[STASH ? 1 : C], hreg[STASH ? 1 : C], Twreg[STASH ? 1 : C];
     double xl, xr;
     // Warm start (src/miz.jl:47,52-54,64).  The reference carries T0 itself between steps; the
@@ -386,6 +371,8 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
         load_chunk<C>(gX, k0, xk);
         xl = gX[k0 > 0 ? k0 - 1 : 0];                     // zero-padded table; unused at the ends
         xr = gX[k0 + C];
+        load_chunk<C>(a.geom + G_LO * a.gstride, k0, tlo);
+        load_chunk<C>(a.geom + G_UP * a.gstride, k0, tup);
 #pragma unroll
         for (int i = 0; i < C; ++i) {
             const bool valid = (int)k0 + i < nlat;
@@ -424,23 +411,11 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
         double gl, gr;
         halo_exchange(P0, P0 + T, t, T, g[0], g[C - 1], gl, gr);
         double ra[C], rb[C], rc[C], rd[C];
-        double tlo[GRID == 0 ? C : 1], tup[GRID == 0 ? C : 1];
-        if constexpr (GRID == 0) {
-            load_chunk<C>(a.geom + G_LO * a.gstride, k0, tlo);
-            load_chunk<C>(a.geom + G_UP * a.gstride, k0, tup);
-        }
 #pragma unroll
         for (int i = 0; i < C; ++i) {
             const int k = (int)k0 + i;
             const bool valid = k < nlat;
-            double lo, up;
-            if (GRID == 0) {
-                lo = tlo[GRID == 0 ? i : 0];
-                up = tup[GRID == 0 ? i : 0];
-            } else {
-                solver_coeffs_nonuniform(p, k, nlat, opaque(i > 0 ? xk[i > 0 ? i - 1 : 0] : xl), opaque(xk[i]),
-                                         opaque(i < C - 1 ? xk[i < C - 1 ? i + 1 : i] : xr), lo, up);
-            }
+            const double lo = tlo[i], up = tup[i];
             // right-hand side: -(ai S - A + Dif((1-phi)(Tw-Tm)) + f), src/miz.jl:39-43
             const double S = p.S0 - p.S1 * xk[i] * a.ct - p.S2 * (xk[i] * xk[i]);   // :11
             const double rm = i > 0 ? r[i > 0 ? i - 1 : 0] : rl;
