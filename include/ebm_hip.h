@@ -58,12 +58,18 @@ enum ebm_param {
 /* fields of `vars` (src/infrastructure.jl:604-605, 621-624) plus the hidden warm start */
 enum ebm_field {
     EBM_F_Ei = 0, EBM_F_Ew, EBM_F_h, EBM_F_D, EBM_F_phi, /* MIZ prognostics (init)          */
-    EBM_F_T0,                                             /* MIZ warm start (src/miz.jl:47)  */
+    EBM_F_T0,                                             /* MIZ warm start (src/miz.jl:47), see below */
     EBM_F_Tw, EBM_F_Ti, EBM_F_n, EBM_F_E, EBM_F_T,        /* MIZ diagnostics; E,T also classic */
     EBM_F_Tg,                                             /* classic ghost layer             */
     EBM_F_COUNT
 };
-/* classic uses EBM_F_E, EBM_F_Tg (prognostic) and EBM_F_T, EBM_F_h (diagnostic). */
+/* classic uses EBM_F_E, EBM_F_Tg (prognostic) and EBM_F_T, EBM_F_h (diagnostic).
+ *
+ * EBM_F_T0: the reference keeps the previous T0 solution as the starting iterate of its nonlinear
+ * solve.  The active-set iteration used here depends on that vector only through its sign pattern
+ * [T0 < Tm], so between steps the library carries that pattern (one bit per cell) and writes the
+ * fp64 EBM_F_T0 field together with the diagnostics (write_diag / diag_last != 0).
+ * ebm_set_field(EBM_F_T0, ...) rebuilds the pattern from the given values. */
 
 /* ---- lifetime ------------------------------------------------------------------------ */
 
