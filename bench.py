@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--spinup", type=int, default=2000)
     ap.add_argument("--workload", default="miz_4096x2048", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU baseline work (0 = skip)")
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU baseline work (0 = skip)")
     args = ap.parse_args()
 
     import torch
