@@ -355,27 +355,56 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
     EBM_STAMP(0);
 
     // ---------------- phase A: loads, water temperature, T0-system coefficients ----------
-    double ph[C], dd[C], r[C], xk[C], tlo[C], tup[C];         // tlo/tup: tridiagonal coefficients of D lap
+    // Only phi and the right-hand side stay in registers across the solve; everything else the
+    // (rare) second and later Newton iterations need is re-read (tables from L2, h from the stash).
+    double ph[C], rd[C];
     double Ewreg[STASH ? 1 : C], hreg[STASH ? 1 : C], Twreg[STASH ? 1 : C];
-    double xl, xr;
     // Warm start (src/miz.jl:47,52-54,64).  The reference carries T0 itself between steps; the
     // active-set iteration only uses its sign pattern, so between steps the library carries that
     // pattern (one bit per cell) and writes the fp64 T0 field on diagnostic launches only.
     unsigned short *const wmask = a.amask + (size_t)col * T + t;
     unsigned smask = *wmask;                              // active set: bit i <=> T0_i < Tm
+    double xs[C];
+    int nit = 0;
+    bool ok = false;
+    // One Newton iteration: rows for the active set `smask`, tridiagonal solve, new active set.
+    auto newton_iteration = [&](const double (&lo)[C], const double (&up)[C], const double (&dd)[C]) -> bool {
+        ++nit;
+        double g[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) g[i] = ((smask >> i) & 1u) ? ph[i] : 0.0;
+        double gl, gr;
+        halo_exchange(P0, P0 + T, t, T, g[0], g[C - 1], gl, gr);
+        double ra[C], rb[C], rc[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            ra[i] = lo[i] * (i > 0 ? g[i > 0 ? i - 1 : 0] : gl);
+            rc[i] = up[i] * (i < C - 1 ? g[i < C - 1 ? i + 1 : i] : gr);
+            rb[i] = -__builtin_fma(lo[i] + up[i], g[i], dd[i]);
+        }
+        EBM_STAMP(4);
+        partition_solve<C>(ra, rb, rc, rd, xs, t, T, P0, P1);
+        EBM_STAMP(5);
+        unsigned snew = 0;
+#pragma unroll
+        for (int i = 0; i < C; ++i) snew |= (xs[i] < 0.0) ? (1u << i) : 0u;
+        const int changed = snew != smask;
+        smask = snew;
+        return __syncthreads_or(changed) != 0;
+    };
+    bool again;
     {
-        double Ew[C], hk[C];
+        double Ew[C], hk[C], xk[C], tlo[C], tup[C], dd[C], r[C];
         load_chunk<C>(st + S_Ew * a.fstride, k0, Ew);
         load_chunk<C>(st + S_phi * a.fstride, k0, ph);
         load_chunk<C>(st + S_h * a.fstride, k0, hk);
         load_chunk<C>(gX, k0, xk);
-        xl = gX[k0 > 0 ? k0 - 1 : 0];                     // zero-padded table; unused at the ends
-        xr = gX[k0 + C];
         load_chunk<C>(a.geom + G_LO * a.gstride, k0, tlo);
         load_chunk<C>(a.geom + G_UP * a.gstride, k0, tup);
+        // Padding cells (k >= nlat) need no special case in phases A and B: their state and table
+        // entries are zero, so their rows are decoupled (lo = up = 0, g = phi = 0) and finite.
 #pragma unroll
         for (int i = 0; i < C; ++i) {
-            const bool valid = (int)k0 + i < nlat;
             double tw = Tm + Ew[i] / ((1.0 - ph[i]) * p.cw);          // water_temp, src/miz.jl:30
             tw = __builtin_isnan(tw) ? 0.0 : tw;                      // :157
             if (STASH) {
@@ -388,57 +417,40 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
                 Twreg[STASH ? 0 : i] = tw;
             }
             const double hp = (hk[i] == 0.0) ? p.hmin : hk[i];        // :51
-            dd[i] = valid ? __builtin_fma(p.k, fast_rcp(hp), p.B) : -1.0;
-            r[i] = valid ? (1.0 - ph[i]) * (tw - Tm) : 0.0;
+            dd[i] = __builtin_fma(p.k, fast_rcp(hp), p.B);
+            r[i] = (1.0 - ph[i]) * (tw - Tm);
         }
-    }
-    EBM_STAMP(1);
-    double rl, rr;
-    halo_exchange(P0, P0 + T, t, T, r[0], r[C - 1], rl, rr);
-    EBM_STAMP(2);
-
-    // ---------------- phase B: active-set Newton, src/miz.jl:33-68 ------------------------
-    double xs[C];
-    int nit = 0;
-    bool ok = false;
-    __syncthreads();                                      // r halo reads done before P0 is reused
-    EBM_STAMP(3);
-    while (nit < kMaxNewton) {
-        ++nit;
-        double g[C];
-#pragma unroll
-        for (int i = 0; i < C; ++i) g[i] = ((smask >> i) & 1u) ? ph[i] : 0.0;
-        double gl, gr;
-        halo_exchange(P0, P0 + T, t, T, g[0], g[C - 1], gl, gr);
-        double ra[C], rb[C], rc[C], rd[C];
+        EBM_STAMP(1);
+        double rl, rr;
+        halo_exchange(P0, P0 + T, t, T, r[0], r[C - 1], rl, rr);
+        EBM_STAMP(2);
+        // right-hand side -(ai S - A + Dif((1-phi)(Tw-Tm)) + f), src/miz.jl:39-43: independent of
+        // the active set, computed once
 #pragma unroll
         for (int i = 0; i < C; ++i) {
-            const int k = (int)k0 + i;
-            const bool valid = k < nlat;
-            const double lo = tlo[i], up = tup[i];
-            // right-hand side: -(ai S - A + Dif((1-phi)(Tw-Tm)) + f), src/miz.jl:39-43
             const double S = p.S0 - p.S1 * xk[i] * a.ct - p.S2 * (xk[i] * xk[i]);   // :11
             const double rm = i > 0 ? r[i > 0 ? i - 1 : 0] : rl;
             const double rp = i < C - 1 ? r[i < C - 1 ? i + 1 : i] : rr;
-            const double dif = __builtin_fma(up, rp - r[i], lo * (rm - r[i]));
-            rd[i] = valid ? -((p.ai * S - p.A) + dif + f) : 0.0;
-            ra[i] = lo * (i > 0 ? g[i > 0 ? i - 1 : 0] : gl);
-            rc[i] = up * (i < C - 1 ? g[i < C - 1 ? i + 1 : i] : gr);
-            rb[i] = -__builtin_fma(lo + up, g[i], dd[i]);
+            const double dif = __builtin_fma(tup[i], rp - r[i], tlo[i] * (rm - r[i]));
+            rd[i] = -((p.ai * S - p.A) + dif + f);
         }
-        EBM_STAMP(4);
-        partition_solve<C>(ra, rb, rc, rd, xs, t, T, P0, P1);
-        EBM_STAMP(5);
-        unsigned snew = 0;
-#pragma unroll
-        for (int i = 0; i < C; ++i) snew |= (xs[i] < 0.0) ? (1u << i) : 0u;
-        const int changed = snew != smask;
-        smask = snew;
-        if (!__syncthreads_or(changed)) {
-            ok = true;
-            break;
-        }
+        __syncthreads();                                  // r halo reads done before P0 is reused
+        EBM_STAMP(3);
+        // ---------------- phase B: active-set Newton, src/miz.jl:33-68 --------------------
+        again = newton_iteration(tlo, tup, dd);
     }
+    while (again && nit < kMaxNewton) {
+        double tlo[C], tup[C], dd[C];
+        load_chunk<C>(a.geom + G_LO * a.gstride, k0, tlo);
+        load_chunk<C>(a.geom + G_UP * a.gstride, k0, tup);
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const double hk = STASH ? sh[i * T] : hreg[STASH ? 0 : i];
+            dd[i] = __builtin_fma(p.k, fast_rcp((hk == 0.0) ? p.hmin : hk), p.B);
+        }
+        again = newton_iteration(tlo, tup, dd);
+    }
+    ok = !again;
     if (t == 0 && a.counters) {
         unsigned long long *cnt = a.counters + 2 * (col % kCounterShards);
         atomicAdd(cnt, (unsigned long long)nit);
@@ -448,6 +460,9 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
     EBM_STAMP(6);
 
     // ---------------- phase D: fluxes and state update ---------------------------------------
+    double xk[C];
+    load_chunk<C>(gX, k0, xk);
+    const double xl = gX[k0 > 0 ? k0 - 1 : 0], xr = gX[k0 + C];     // zero-padded table; unused at the ends
     double g0[GRID == 0 ? C : 1], g1[GRID == 0 ? C : 1], g2[GRID == 0 ? C : 1];
     if constexpr (GRID == 0) {
         load_chunk<C>(a.geom + G_0 * a.gstride, k0, g0);
