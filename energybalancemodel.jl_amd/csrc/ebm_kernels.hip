@@ -388,6 +388,8 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
         unsigned snew = 0;
 #pragma unroll
         for (int i = 0; i < C; ++i) snew |= (xs[i] < 0.0) ? (1u << i) : 0u;
+        const int nvalid = nlat - (int)k0;                // padding rows never count as a change
+        snew &= nvalid >= C ? ~0u : (nvalid > 0 ? (1u << nvalid) - 1u : 0u);
         const int changed = snew != smask;
         smask = snew;
         return __syncthreads_or(changed) != 0;
