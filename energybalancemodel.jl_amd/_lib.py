@@ -27,6 +27,7 @@ EXPORTS = (
     "ebm_get_field", "ebm_field_device_ptr", "ebm_set_column_forcing", "ebm_set_time_table",
     "ebm_step", "ebm_run", "ebm_integrate", "ebm_sync", "ebm_get_counters",
     "ebm_reset_counters", "ebm_timer_start", "ebm_timer_stop", "ebm_launch_info",
+    "ebm_selftest_divide",
 )
 
 _dp = C.POINTER(C.c_double)
@@ -69,6 +70,7 @@ def load():
     lib.ebm_timer_start.argtypes = [C.c_void_p]
     lib.ebm_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.ebm_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    lib.ebm_selftest_divide.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
     _lib = lib
     return lib
 

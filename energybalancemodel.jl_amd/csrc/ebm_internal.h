@@ -71,6 +71,7 @@ hipError_t launch_classic_step(const StepArgs &a, int ncol, const LaunchCfg &cfg
 // savesol! helpers: sum[i] += src[i] ; dst[i] = sum[i]/nt, sum[i] = 0
 // active set from the T0 field (after ebm_set_field(T0))
 hipError_t launch_mask_from_t0(const StepArgs &a, int ncol, const LaunchCfg &cfg, hipStream_t s);
+hipError_t launch_divide(const double *a, const double *b, double *q, int n, hipStream_t s);
 hipError_t launch_accumulate(double *sum, const double *src, size_t n, hipStream_t s);
 hipError_t launch_finish_mean(double *dst, double *sum, double nt, size_t n, hipStream_t s);
 

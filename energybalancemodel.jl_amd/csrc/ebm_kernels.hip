@@ -56,6 +56,28 @@ __device__ __forceinline__ double bool_mul(double x, bool b) {
     return b ? x : __builtin_copysign(0.0, x);   // Bool "strong zero"
 }
 
+// IEEE fp64 division for the bit-exact physics.  hipcc expands a/b to v_div_scale x2, v_rcp_f64,
+// two Newton steps, a residual correction, v_div_fmas and v_div_fixup.  The two scalings and
+// div_fmas only act when an operand or the quotient is near the exponent limits; for every other
+// input the sequence below (the same instructions without the scaling) returns the same bits, and
+// v_div_fixup still produces the IEEE results for zero, infinite and NaN operands.
+// -DEBM_FULL_DIV selects the compiler's expansion instead.
+__device__ __forceinline__ double ieee_div(double a, double b) {
+#ifdef EBM_FULL_DIV
+    return a / b;
+#else
+    const double r0 = __builtin_amdgcn_rcp(b);
+    const double e0 = __builtin_fma(-b, r0, 1.0);
+    const double r1 = __builtin_fma(r0, e0, r0);
+    const double e1 = __builtin_fma(-b, r1, 1.0);
+    const double r2 = __builtin_fma(r1, e1, r1);
+    const double q0 = a * r2;
+    const double rem = __builtin_fma(-b, q0, a);
+    const double q = __builtin_fma(rem, r2, q0);
+    return __builtin_amdgcn_div_fixup(q, b, a);
+#endif
+}
+
 // ---- solver arithmetic (not order-constrained) ---------------------------------------------
 __device__ __forceinline__ double fast_rcp(double x) {
     double r = __builtin_amdgcn_rcp(x);
@@ -213,7 +235,7 @@ __device__ __forceinline__ MizCellOut miz_cell_update(const Params &p, double f,
                                                      double Ti) {
     const double Tm = p.Tm, Lf = p.Lf, alpha = p.alpha, dt = p.dt;
     // num, src/miz.jl:83-87
-    double n = ph / (alpha * (Dk * Dk));
+    double n = ieee_div(ph, alpha * (Dk * Dk));
     if (Dk == 0.0) n = 0.0;
     // vert_flux, src/miz.jl:96-101 (called twice in the reference with the same Tbar/diffusion)
     const double L = p.A + p.B * (tb - Tm);
@@ -223,7 +245,7 @@ __device__ __forceinline__ MizCellOut miz_cell_update(const Params &p, double f,
     const double Fvw = sol_w - L + dif + p.Fb + f;
     // wlat :71, lat_flux :103-107
     const double wl = p.m1 * (Tw - p.Tm_pow_m2);
-    double Flat = ph * hk * Lf * wl * M_PI / (alpha * Dk);
+    double Flat = ieee_div(ph * hk * Lf * wl * M_PI, alpha * Dk);
     if (Dk == 0.0) Flat = 0.0;
     // forward Euler (:137-138,148,166-167) and redistributeE (:109-117)
     const double rEi = Ei + (ph * Fvi + Flat) * dt;
@@ -238,31 +260,31 @@ __device__ __forceinline__ MizCellOut miz_cell_update(const Params &p, double f,
     const double ring = alpha * n * (Dr * Dr - Dk * Dk);
     const double Al = jl_min(ring, 1.0 - ph);
     // split_psiEw :120-125 applied to psiEwdt/dt (:173)
-    const double psi = psiEwdt / dt;
-    double Ql = Al / (1.0 - ph) * psi;
+    const double psi = ieee_div(psiEwdt, dt);
+    double Ql = ieee_div(Al, 1.0 - ph) * psi;
     if (ph == 1.0) Ql = 0.0;
     const double Qp = psi - Ql;
     // psinplus :127, :174
-    const double dn = dt * (-Qp / p.c_dn);
+    const double dn = dt * ieee_div(-Qp, p.c_dn);
     // D_t :140-146
     const double lat_melt = p.c_latmelt * wl;
-    double lat_grow = -Dk / (2.0 * Lf * hk * ph) * Ql;
+    double lat_grow = ieee_div(-Dk, 2.0 * Lf * hk * ph) * Ql;
     const double weld = p.c_weld * ph * (Dk * Dk * Dk);
     if (hk == 0.0) lat_grow = 0.0;
     const double rD = Dk + (lat_melt + lat_grow + weld) * dt;
     // average :129-134, clamp!, zeroref! (:175-178)
     const double total = n + dn;
-    double D_n = (n * rD + dn * p.Dmin) / total;
+    double D_n = ieee_div(n * rD + dn * p.Dmin, total);
     if (total == 0.0) D_n = 0.0;
     D_n = jl_clamp(D_n, p.Dmin, p.Dmax);
     if (Ei_n == 0.0) D_n = 0.0;
     // thickness :179-181
     double rh = hk + (p.c_ht * Fvi) * dt;
     rh = jl_clamp(rh, 0.0, INFINITY);
-    double h_n = (n * rh + dn * p.hmin) / total;
+    double h_n = ieee_div(n * rh + dn * p.hmin, total);
     if (total == 0.0) h_n = 0.0;
     // concentration :74-80
-    double phi_n = -Ei_n / (Lf * h_n);
+    double phi_n = ieee_div(-Ei_n, Lf * h_n);
     if (h_n == 0.0) phi_n = 0.0;
     if (phi_n > 1.0) phi_n = 1.0;
     if (h_n == 0.0) Ei_n = 0.0;   // :185
@@ -295,7 +317,7 @@ __device__ __forceinline__ double diffusion_add(double base, double D, int k, in
     } else {
         const double dTp = (k < nlat - 1) ? tbp - tbk : 0.0;
         const double dTm = (k > 0) ? tbk - tbm : 0.0;
-        return base + (D * ((g0 * dTp) / g2 - (g1 * dTm) / g3)) / g4;
+        return base + ieee_div(D * (ieee_div(g0 * dTp, g2) - ieee_div(g1 * dTm, g3)), g4);
     }
 }
 
@@ -407,7 +429,7 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
         // entries are zero, so their rows are decoupled (lo = up = 0, g = phi = 0) and finite.
 #pragma unroll
         for (int i = 0; i < C; ++i) {
-            double tw = Tm + Ew[i] / ((1.0 - ph[i]) * p.cw);          // water_temp, src/miz.jl:30
+            double tw = Tm + ieee_div(Ew[i], (1.0 - ph[i]) * p.cw);   // water_temp, src/miz.jl:30
             tw = __builtin_isnan(tw) ? 0.0 : tw;                      // :157
             if (STASH) {
                 sEw[i * T] = Ew[i];
@@ -634,6 +656,17 @@ __global__ void mask_from_t0_kernel(const StepArgs a, int C) {
     for (int i = 0; i < C; ++i)
         if (t * C + i < a.nlat && T0[i] < Tm) m |= 1u << i;
     a.amask[(size_t)col * T + t] = (unsigned short)m;
+}
+
+// Self-test hook (ebm_selftest_divide): q[i] = ieee_div(a[i], b[i]) with the device routine the
+// physics uses, so that tests can compare it bit for bit with host IEEE division.
+__global__ void divide_kernel(const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ q, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) q[i] = ieee_div(a[i], b[i]);
+}
+hipError_t launch_divide(const double *a, const double *b, double *q, int n, hipStream_t s) {
+    divide_kernel<<<(n + 255) / 256, 256, 0, s>>>(a, b, q, n);
+    return hipGetLastError();
 }
 
 // ---- savesol! helpers (src/infrastructure.jl:549-591, src/utilities.jl:390-395) ---------------

@@ -517,6 +517,24 @@ int ebm_debug_stamps(ebm_handle_t h, unsigned long long *host) {
 }
 #endif
 
+int ebm_selftest_divide(int device, int n, const double *a, const double *b, double *q) {
+    if (n < 0 || !a || !b || !q) return fail(EBM_ERR_ARG, "ebm_selftest_divide: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(EBM_ERR_NO_DEVICE, "ebm_selftest_divide: no HIP device available");
+    HIPCHK(hipSetDevice(device));
+    double *da = nullptr, *db = nullptr, *dq = nullptr;
+    const size_t nb = sizeof(double) * (size_t)n;
+    HIPCHK(hipMalloc(&da, nb)); HIPCHK(hipMalloc(&db, nb)); HIPCHK(hipMalloc(&dq, nb));
+    HIPCHK(hipMemcpy(da, a, nb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(db, b, nb, hipMemcpyHostToDevice));
+    hipError_t e = ebm::launch_divide(da, db, dq, n, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(q, dq, nb, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dq);
+    if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("ebm_selftest_divide: ") + hipGetErrorString(e));
+    return EBM_OK;
+}
+
 int ebm_launch_info(ebm_handle_t h, int *info) {
     if (!h || !info) return fail(EBM_ERR_ARG, "ebm_launch_info: null argument");
     info[0] = h->cfg.threads;

@@ -139,6 +139,9 @@ int ebm_timer_stop(ebm_handle_t h, float *elapsed_ms);
 /* Launch geometry chosen for this handle: info[0] threads per workgroup, [1] cells per
  * thread, [2] dynamic LDS bytes per workgroup, [3] workgroups per launch. */
 int ebm_launch_info(ebm_handle_t h, int *info);
+/* Self-test: q[i] = a[i] / b[i] computed on the device with the division routine the physics
+ * kernels use (bit-exact IEEE fp64 division is part of the parity contract). */
+int ebm_selftest_divide(int device, int n, const double *a, const double *b, double *q);
 
 #ifdef __cplusplus
 }

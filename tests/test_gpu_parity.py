@@ -330,6 +330,34 @@ def test_classic_sizes_vs_oracle(pkg, coracle, nlat, ncol):
     check_all(got, ref, size_tol(TOL_SHORT, nlat), names=("E", "Tg", "T", "h"), what=f"classic {nlat}x{ncol}")
 
 
+def test_device_division_is_ieee(pkg):
+    """The physics is a bit-exact restatement only if the device's fp64 division is IEEE: the
+    kernels use a rcp + Newton + residual + v_div_fixup sequence without the exponent rescaling of
+    the compiler's expansion.  It must equal host division bit for bit for every operand whose
+    magnitude (and quotient) is within 2^+-500, and for zero / infinite / NaN operands."""
+    from energybalancemodel_jl_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    n = 1 << 20
+    a = rng.normal(size=n) * 2.0 ** rng.integers(-250, 250, n)
+    b = rng.normal(size=n) * 2.0 ** rng.integers(-250, 250, n)
+    # near-halfway and physically typical operands
+    a[:1000] = 1.0 + rng.integers(0, 1 << 20, 1000) * 2.0 ** -52
+    b[:1000] = 3.0 + rng.integers(0, 1 << 20, 1000) * 2.0 ** -51
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 9.5, 1e-300, 1e300])
+    aa, bb = np.meshgrid(special, special)
+    a[1000:1100], b[1000:1100] = aa.ravel(), bb.ravel()
+    q = np.empty(n)
+    _lib.check(lib.ebm_selftest_divide(0, n, _lib.dptr(a), _lib.dptr(b), _lib.dptr(q)), "ebm_selftest_divide")
+    with np.errstate(all="ignore"):
+        ref = a / b
+    moderate = np.ones(n, bool)
+    moderate[1000:1100] = ~((np.abs(aa.ravel()) == 1e-300) | (np.abs(aa.ravel()) == 1e300) |
+                            (np.abs(bb.ravel()) == 1e-300) | (np.abs(bb.ravel()) == 1e300))
+    same = (q.view(np.uint64) == ref.view(np.uint64)) | (np.isnan(q) & np.isnan(ref))
+    assert same[moderate].all(), int((~same[moderate]).sum())
+
+
 # ---- the reference's operator surface ------------------------------------------------------------
 def test_step_bang_surface(pkg):
     """step!(Val(:MIZ), t, f, vars, st, par) called directly, 10 times from the zero state
