@@ -93,11 +93,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # one rank per GPU; EBM_BENCH_BACKEND=gloo lets several ranks share a device to rehearse the
+    # N > 1 path on a one-GPU box (RCCL refuses two ranks on one device)
+    backend = os.environ.get("EBM_BENCH_BACKEND", "nccl")
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
 
     pkg = graft.load_package()
     wl = WORKLOADS[args.workload]
@@ -107,7 +114,7 @@ def main():
     lon = np.arange(ncol) + rank * ncol                      # this rank's block of columns
     fcol = 0.5 * np.sin(2.0 * np.pi * lon / ncol)
     eng = pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval),
-                     st.dt, ncol, device=local_rank)
+                     st.dt, ncol, device=device)
     if model == "Classic":
         Ts = 30.0 - 45.0 * st.x ** 2
         E0 = np.where(Ts >= 0, par["cw"] * Ts, par["Lf"] * Ts / 7.5)
@@ -144,7 +151,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     cnt = eng.counters()
