@@ -68,11 +68,24 @@ hipError_t prepare_kernels(const LaunchCfg &cfg);   // raises the dynamic-LDS li
 hipError_t launch_miz_step(const StepArgs &a, int max_groups, int grid_kind, const LaunchCfg &cfg, hipStream_t s);
 int miz_groups_per_cu(const LaunchCfg &cfg);
 hipError_t launch_classic_step(const StepArgs &a, int ncol, const LaunchCfg &cfg, hipStream_t s);
-// savesol! helpers: sum[i] += src[i] ; dst[i] = sum[i]/nt, sum[i] = 0
+// savesol! (src/infrastructure.jl:549-591) for one step, all saved variables in one launch:
+// running sums for the annual mean (padded [nvars][ncol*pitch] layout) and/or a packed snapshot
+// into the raw staging buffer ([nvars][chunk][ncol][nlat], snapshot index `stage_index`).
+struct SaveArgs {
+    const double *state;
+    long long fstride;
+    int slots[12];
+    int nvars, pitch, nlat, ncol;
+    double *sums;            // or nullptr
+    long long sum_stride;    // ncol*pitch
+    double *stage;           // or nullptr
+    long long stage_var_stride, stage_index;
+};
+hipError_t launch_savesol(const SaveArgs &a, hipStream_t s);
 // active set from the T0 field (after ebm_set_field(T0))
 hipError_t launch_mask_from_t0(const StepArgs &a, int ncol, const LaunchCfg &cfg, hipStream_t s);
 hipError_t launch_divide(const double *a, const double *b, double *q, int n, hipStream_t s);
-hipError_t launch_accumulate(double *sum, const double *src, size_t n, hipStream_t s);
+// dst[i] = sum[i]/nt, sum[i] = 0
 hipError_t launch_finish_mean(double *dst, double *sum, double nt, size_t n, hipStream_t s);
 
 }  // namespace ebm

@@ -670,9 +670,17 @@ hipError_t launch_divide(const double *a, const double *b, double *q, int n, hip
 }
 
 // ---- savesol! helpers (src/infrastructure.jl:549-591, src/utilities.jl:390-395) ---------------
-__global__ void accumulate_kernel(double *__restrict__ sum, const double *__restrict__ src, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        sum[i] = sum[i] + src[i];
+__global__ void savesol_kernel(const SaveArgs a) {
+    const size_t ncell = (size_t)a.ncol * a.nlat;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < ncell; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t col = e / a.nlat, k = e - col * a.nlat;
+        const size_t src = col * a.pitch + k;
+        for (int v = 0; v < a.nvars; ++v) {
+            const double x = a.state[(size_t)a.slots[v] * a.fstride + src];
+            if (a.sums) a.sums[(size_t)v * a.sum_stride + src] += x;      // crossmean, src/utilities.jl:390-395
+            if (a.stage) a.stage[(size_t)v * a.stage_var_stride + (size_t)a.stage_index * ncell + e] = x;
+        }
+    }
 }
 __global__ void finish_mean_kernel(double *__restrict__ dst, double *__restrict__ sum, double nt, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -782,10 +790,11 @@ hipError_t launch_mask_from_t0(const StepArgs &a, int ncol, const LaunchCfg &cfg
     return hipGetLastError();
 }
 
-hipError_t launch_accumulate(double *sum, const double *src, size_t n, hipStream_t s) {
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    accumulate_kernel<<<blocks, 256, 0, s>>>(sum, src, n);
+hipError_t launch_savesol(const SaveArgs &a, hipStream_t s) {
+    const size_t ncell = (size_t)a.ncol * a.nlat;
+    int blocks = (int)((ncell + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    savesol_kernel<<<blocks, 256, 0, s>>>(a);
     return hipGetLastError();
 }
 hipError_t launch_finish_mean(double *dst, double *sum, double nt, size_t n, hipStream_t s) {

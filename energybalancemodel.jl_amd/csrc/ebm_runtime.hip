@@ -352,7 +352,7 @@ int ebm_run(ebm_handle_t h, long long first_step, int nsteps, const double *f_st
 int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int lastonly,
                   int winter_inx, int summer_inx, int nvars, const int *fields, double *raw,
                   double *winter, double *summer, double *avg) {
-    if (!h || nt < 1 || dur < 1 || nvars < 0 || (nvars > 0 && !fields)) return fail(EBM_ERR_ARG, "ebm_integrate: bad argument");
+    if (!h || nt < 1 || dur < 1 || nvars < 0 || nvars > 12 || (nvars > 0 && !fields)) return fail(EBM_ERR_ARG, "ebm_integrate: bad argument");
     if ((long long)h->ttab.size() != nt) return fail(EBM_ERR_ARG, "ebm_integrate: time table length must equal nt");
     for (int v = 0; v < nvars; ++v)
         if (!has_field(h, fields[v])) return fail(EBM_ERR_ARG, "ebm_integrate: field not part of this model");
@@ -412,16 +412,18 @@ int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int la
         const double f = f_steps ? f_steps[tinx - 1] : 0.0;
         int rc = do_step(h, h->ttab[ti - 1], h->ttab[ti % nt], f, 1);
         if (rc) { cleanup(); return rc; }
-        // savesol!, src/infrastructure.jl:549-591
-        if (sums)
-            for (int v = 0; v < nvars; ++v)
-                EBM_TRY(ebm::launch_accumulate(sums + (size_t)v * npitch, h->field[fields[v]], npitch, h->stream));
-        if (stage && (!lastonly || tinx > total - nt)) {
-            for (int v = 0; v < nvars; ++v)
-                EBM_TRY(hipMemcpy2DAsync(stage + ((size_t)v * chunk + staged) * ncell, sizeof(double) * h->nlat,
-                                         h->field[fields[v]], sizeof(double) * h->pitch, sizeof(double) * h->nlat,
-                                         h->ncol, hipMemcpyDeviceToDevice, h->stream));
-            if (++staged == chunk) EBM_TRY(flush());
+        // savesol!, src/infrastructure.jl:549-591: annual-mean sums and raw snapshot in one launch
+        const bool want_raw = stage && (!lastonly || tinx > total - nt);
+        if (sums || want_raw) {
+            ebm::SaveArgs sa{};
+            sa.state = h->state; sa.fstride = h->fstride;
+            for (int v = 0; v < nvars; ++v) sa.slots[v] = slot_of(h->model, fields[v]);
+            sa.nvars = nvars; sa.pitch = (int)h->pitch; sa.nlat = h->nlat; sa.ncol = h->ncol;
+            sa.sums = sums; sa.sum_stride = (long long)npitch;
+            sa.stage = want_raw ? stage : nullptr;
+            sa.stage_var_stride = (long long)(chunk * (long long)ncell); sa.stage_index = staged;
+            EBM_TRY(ebm::launch_savesol(sa, h->stream));
+            if (want_raw && ++staged == chunk) EBM_TRY(flush());
         }
         if (ti == winter_inx) {
             if (winter)
