@@ -64,9 +64,7 @@ constexpr int kMaxNewton = 50;
 
 LaunchCfg choose_launch(int nlat, bool prefer_c8);
 hipError_t prepare_kernels(const LaunchCfg &cfg);   // raises the dynamic-LDS limit if needed
-// MIZ: persistent workgroups, `max_groups` = CUs x resident workgroups per CU
-hipError_t launch_miz_step(const StepArgs &a, int max_groups, int grid_kind, const LaunchCfg &cfg, hipStream_t s);
-int miz_groups_per_cu(const LaunchCfg &cfg);
+hipError_t launch_miz_step(const StepArgs &a, int grid_kind, const LaunchCfg &cfg, hipStream_t s);   // one workgroup per column
 hipError_t launch_classic_step(const StepArgs &a, int ncol, const LaunchCfg &cfg, hipStream_t s);
 // savesol! (src/infrastructure.jl:549-591) for one step, all saved variables in one launch:
 // running sums for the annual mean (padded [nvars][ncol*pitch] layout) and/or a packed snapshot

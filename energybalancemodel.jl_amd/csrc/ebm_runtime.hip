@@ -185,7 +185,7 @@ int do_step(ebm_ctx *h, double ct, double ct_next, double f, int write_diag) {
     a.ct = ct; a.ct_next = ct_next; a.ft = f; a.write_diag = write_diag;
     a.stamps = h->stamps;
     hipError_t e = (h->model == EBM_MODEL_MIZ)
-                       ? ebm::launch_miz_step(a, h->num_cus * ebm::miz_groups_per_cu(h->cfg), h->grid, h->cfg, h->stream)
+                       ? ebm::launch_miz_step(a, h->grid, h->cfg, h->stream)
                        : ebm::launch_classic_step(a, h->ncol, h->cfg, h->stream);
     if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     h->n_steps += 1;
