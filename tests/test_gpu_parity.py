@@ -211,6 +211,30 @@ def test_miz_sizes_vs_oracle(pkg, coracle, kind, nlat, ncol, nt, spin, nsteps):
     assert cnt["solves"] == ocnt[0] and cnt["cap_hits"] == 0     # same active-set iteration path
 
 
+def test_alternative_geometry_512x8(pkg, coracle, monkeypatch):
+    """EBM_CELLS_PER_THREAD=8 selects 512 threads x 8 cells for 2048 < nlat <= 4096 (a tuning knob:
+    slower on MI355X, kept as a tested alternative).  Same results as the default geometry."""
+    nlat, ncol, nt, spin, nsteps = 4096, 3, 1048576, 30, 5
+    st = pkg.SpaceTime("sin", nlat, nt, 1)
+    par = pkg.default_parameters("MIZ")
+    fcol = np.array([-1.0, 0.0, 1.5])
+    state = {k: np.zeros((ncol, nlat)) for k in PROG + ("T0",)}
+    ct = ctab(pkg, st)
+    coracle.miz_run(1, st.x, dict(par), st.dt, ct[:spin], np.zeros(spin), fcol, state)
+    monkeypatch.setenv("EBM_CELLS_PER_THREAD", "8")
+    with make_engine(pkg, "MIZ", st, par, ncol) as eng:
+        assert eng.launch_info()["cells_per_thread"] == 8 and eng.launch_info()["threads"] == 512
+        eng.set_state(state)
+        eng.set_column_forcing(fcol)
+        eng.set_time_table(st.t)
+        eng.run(spin, nsteps)
+        got = eng.get_state(ALL)
+    diag, _ = coracle.miz_run(1, st.x, dict(par), st.dt, ct[spin:spin + nsteps], np.zeros(nsteps), fcol, state)
+    ref = dict(state)
+    ref.update(diag)
+    check_all(got, ref, size_tol(TOL_SHORT, nlat), what="512x8 geometry")
+
+
 def test_unsupported_and_bad_arguments(pkg):
     st = pkg.SpaceTime("sin", 8200, 100, 1)
     with pytest.raises(pkg.EBMError, match="not supported"):

@@ -37,6 +37,31 @@ def test_no_gpu_fails_loudly(pkg):
         pkg.step_("MIZ", 0.00025, 0.0, init, st, pkg.default_parameters("MIZ"))
 
 
+def test_create_rejects_bad_arguments_before_touching_the_device(pkg):
+    """Argument checks come first, so they are observable without a GPU: empty / degenerate
+    grids, non-positive dt, unknown model or grid tags, null pointers."""
+    from energybalancemodel_jl_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    x = np.linspace(0.01, 0.99, 16)
+    par = np.zeros(len(_lib.PARAM_ORDER))
+    h = C.c_void_p()
+
+    def create(model=0, grid=1, nlat=16, ncol=1, dt=1e-3, xp=x, pp=par):
+        return lib.ebm_create(C.byref(h), model, grid, nlat, ncol, _lib.dptr(xp), _lib.dptr(pp), dt, 0)
+
+    for kw, msg in ((dict(nlat=1), b"nlat >= 2"), (dict(nlat=0), b"nlat >= 2"), (dict(ncol=0), b"ncol >= 1"),
+                    (dict(dt=0.0), b"dt must be positive"), (dict(dt=-1.0), b"dt must be positive"),
+                    (dict(model=7), b"unknown model"), (dict(grid=5), b"unknown grid"),
+                    (dict(xp=None), b"null argument")):
+        assert create(**kw) == -1, kw                       # EBM_ERR_ARG
+        assert msg in lib.ebm_last_error(), (kw, lib.ebm_last_error())
+        assert not h.value
+    assert lib.ebm_destroy(None) == 0                       # destroying a null handle is a no-op
+    for fn in (lib.ebm_sync, lib.ebm_timer_start, lib.ebm_reset_counters):
+        assert fn(None) == -1
+
+
 def test_product_does_not_import_oracle():
     """The package must not reference oracle/ (the oracle is test infrastructure)."""
     pdir = os.path.join(ROOT, "energybalancemodel.jl_amd")
