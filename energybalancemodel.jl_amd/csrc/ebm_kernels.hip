@@ -78,19 +78,28 @@ __device__ __forceinline__ double bool_mul(double x, bool b) {
 // input the sequence below (the same instructions without the scaling) returns the same bits, and
 // v_div_fixup still produces the IEEE results for zero, infinite and NaN operands.
 // -DEBM_FULL_DIV selects the compiler's expansion instead.
-__device__ __forceinline__ double ieee_div(double a, double b) {
-#ifdef EBM_FULL_DIV
-    return a / b;
-#else
+__device__ __forceinline__ double div_rcp(double b) {     // refined reciprocal of the sequence
     const double r0 = __builtin_amdgcn_rcp(b);
     const double e0 = __builtin_fma(-b, r0, 1.0);
     const double r1 = __builtin_fma(r0, e0, r0);
     const double e1 = __builtin_fma(-b, r1, 1.0);
-    const double r2 = __builtin_fma(r1, e1, r1);
+    return __builtin_fma(r1, e1, r1);
+}
+__device__ __forceinline__ double div_with_rcp(double a, double b, double r2) {
+#ifdef EBM_FULL_DIV
+    return a / b;
+#else
     const double q0 = a * r2;
     const double rem = __builtin_fma(-b, q0, a);
     const double q = __builtin_fma(rem, r2, q0);
     return __builtin_amdgcn_div_fixup(q, b, a);
+#endif
+}
+__device__ __forceinline__ double ieee_div(double a, double b) {
+#ifdef EBM_FULL_DIV
+    return a / b;
+#else
+    return div_with_rcp(a, b, div_rcp(b));
 #endif
 }
 
@@ -283,14 +292,15 @@ __device__ __forceinline__ MizCellOut miz_cell_update(const Params &p, double f,
     const double rD = Dk + (lat_melt + lat_grow + weld) * dt;
     // average :129-134, clamp!, zeroref! (:175-178)
     const double total = n + dn;
-    double D_n = ieee_div(n * rD + dn * p.Dmin, total);
+    const double rtotal = div_rcp(total);                 // D_n and h_n divide by the same total
+    double D_n = div_with_rcp(n * rD + dn * p.Dmin, total, rtotal);
     if (total == 0.0) D_n = 0.0;
     D_n = jl_clamp(D_n, p.Dmin, p.Dmax);
     if (Ei_n == 0.0) D_n = 0.0;
     // thickness :179-181
     double rh = hk + (p.c_ht * Fvi) * dt;
     rh = jl_clamp(rh, 0.0, INFINITY);
-    double h_n = ieee_div(n * rh + dn * p.hmin, total);
+    double h_n = div_with_rcp(n * rh + dn * p.hmin, total, rtotal);
     if (total == 0.0) h_n = 0.0;
     // concentration :74-80
     double phi_n = ieee_div(-Ei_n, Lf * h_n);
@@ -324,29 +334,33 @@ __device__ __forceinline__ double diffusion_add(double base, double D, int k, in
         y = (k < nlat - 1) ? y + g2 * tbp : y;
         return base + y;
     } else {
+        // flux form with table geometry (the MIZ kernel evaluates it per interface instead,
+        // see interface_flux)
         const double dTp = (k < nlat - 1) ? tbp - tbk : 0.0;
         const double dTm = (k > 0) ? tbk - tbm : 0.0;
         return base + ieee_div(D * (ieee_div(g0 * dTp, g2) - ieee_div(g1 * dTm, g3)), g4);
     }
 }
 
-// Geometry of the non-uniform stencil from x alone (src/infrastructure.jl:510-518), evaluated
-// with the same IEEE operations, in the same order, as the host-side tables — bit-identical to
-// them, and cheaper than loading five more per-latitude vectors.  xm/xk/xp = x at k-1, k, k+1.
-struct SinGeom {
-    double mph, mmh, dxp, dxm, w;
-};
-__device__ __forceinline__ SinGeom sin_geometry(int k, int nlat, double xm, double xk, double xp) {
-    xm = k > 0 ? xm : -xk;                  // ghost cell [-x[1]; x; 2-x[end]]
-    xp = k < nlat - 1 ? xp : 2.0 - xk;
-    const double xxph = (xp + xk) / 2.0, xxmh = (xk + xm) / 2.0;
-    SinGeom g;
-    g.mph = 1.0 - xxph * xxph;
-    g.mmh = 1.0 - xxmh * xxmh;
-    g.dxp = xp - xk;
-    g.dxm = xk - xm;
-    g.w = xxph - xxmh;
-    return g;
+// Flux through the interface between cells kI-1 (x = xa, T = tba) and kI (x = xb, T = tbb) of the
+// non-uniform stencil, src/infrastructure.jl:510-524: (1 - xx^2) dT / dx with the ghost cells
+// [-x[1]; x; 2-x[end]] and dT = 0 at the two ends.  Cell k-1 computes it as (mxxph*diffT[i])/diffx[i]
+// and cell k as (mxxmh*diffT[i-1])/diffx[i-1]: the same operands in the same order, hence the same
+// bits — so it is evaluated once per interface instead of twice.  Also returns xx, the interface
+// position (xxph of the left cell, xxmh of the right one).
+__device__ __forceinline__ double interface_flux(int kI, int nlat, double xa, double xb, double tba,
+                                                 double tbb, double &xx) {
+    double lo_x = xa, hi_x = xb, dT = tbb - tba;
+    if (kI <= 0) {             // equator: xm = -x[1], diffT[1] = 0
+        lo_x = -xb;
+        dT = 0.0;
+    }
+    if (kI >= nlat) {          // pole: xp = 2 - x[end], diffT[end] = 0
+        hi_x = 2.0 - xa;
+        dT = 0.0;
+    }
+    xx = (hi_x + lo_x) / 2.0;
+    return ieee_div((1.0 - xx * xx) * dT, hi_x - lo_x);
 }
 
 // MIZ step: one workgroup per meridian.
@@ -525,6 +539,8 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
     // then (cells 0,1 of the stash, the idle tail of the cyclic-reduction buffers) and all 32 bytes
     // of a lane go out in two back-to-back 16-B stores once the second pair is done.
     constexpr bool WHOLE = STASH && C == 4;
+    double Fl = 0.0, xxl = 0.0;                           // flux / position of the interface left of the current cell
+    if (GRID == 1) Fl = interface_flux((int)k0, nlat, xl, xk[0], tbl, tb[0], xxl);
     double *const park0 = P0 + 2 * T + t;                 // P0[2T..3T), P1[0..3T): clear of the halo words
 #pragma unroll
     for (int j = 0; j < C / 2; ++j) {
@@ -538,7 +554,6 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
             const int i = 2 * j + q, k = (int)k0 + i;
             const double tbm = i > 0 ? tb[i > 0 ? i - 1 : 0] : tbl;
             const double tbp = i < C - 1 ? tb[i < C - 1 ? i + 1 : i] : tbr;
-            const double xm = i > 0 ? xk[i > 0 ? i - 1 : 0] : xl;
             const double xp = i < C - 1 ? xk[i < C - 1 ? i + 1 : i] : xr;
             const double S = p.S0 - p.S1 * xk[i] * a.ct - p.S2 * (xk[i] * xk[i]);
             double dif;
@@ -546,9 +561,11 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
                 dif = diffusion_add<0>(0.0, p.D, k, nlat, g0[GRID == 0 ? i : 0], g1[GRID == 0 ? i : 0],
                                        g2[GRID == 0 ? i : 0], 0.0, 0.0, tbm, tb[i], tbp);
             } else {
-                const SinGeom sg = sin_geometry(k, nlat, xm, xk[i], xp);
-                dif = diffusion_add<1>(0.0, p.D, k, nlat, sg.mph, sg.mmh, sg.dxp, sg.dxm, sg.w, tbm, tb[i],
-                                       tbp);
+                double xxr;
+                const double Fr = interface_flux(k + 1, nlat, xk[i], xp, tb[i], tbp, xxr);
+                dif = 0.0 + ieee_div(p.D * (Fr - Fl), xxr - xxl);         // :524
+                Fl = Fr;
+                xxl = xxr;
             }
             const double Ewk = STASH ? sEw[i * T] : Ewreg[STASH ? 0 : i];
             const double hk = STASH ? sh[i * T] : hreg[STASH ? 0 : i];
