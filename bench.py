@@ -194,6 +194,10 @@ def main():
             "kernel": "miz_step_kernel" if model == "MIZ" else "classic_step_kernel",
             "algorithmic_bytes_per_launch": bpc * cells,
             "avg_launch_ms": launch_s * 1e3,
+            # transparency: the kernel carries the T0 warm start as a bit mask, so it moves fewer bytes
+            # than the contract's 96 B per cell-step; this is the rate of the counter-measured traffic
+            "achieved_traffic_gbs": (traffic / launch_s / 1e9) if traffic else None,
+            "frac_traffic": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
         },
         "cpu_baseline": cpu,
     }
