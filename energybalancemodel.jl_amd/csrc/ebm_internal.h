@@ -38,6 +38,12 @@ enum ClassicSlot { C_E = 0, C_Tg, C_T, C_h, C_COUNT };
 //   G_KSUB..G_SB     classic: kappa's three diagonals, aw, S base (src/classic.jl:21-28)
 enum GeomTable { G_X = 0, G_0, G_1, G_2, G_3, G_4, G_LO, G_DI, G_UP, G_KSUB, G_KDIAG, G_KSUP, G_AW, G_SB, G_COUNT };
 
+// Per-step scalars of a graph-replayed step: kernel node `slot` of the replayed graph reads entry
+// `slot` of a small device table that the host refills before every replay.
+struct StepSched {
+    double ct, ct_next, ft;
+};
+
 struct StepArgs {
     double *state;
     long long fstride;
@@ -49,6 +55,8 @@ struct StepArgs {
     unsigned short *amask;           // MIZ warm start as an active set: [ncol][threads], bit i <=> T0 < Tm in cell i of the thread
     int pitch, nlat, ncol;
     double ct, ct_next, ft;          // cos(2 pi t) [MIZ / classic column i], classic column i+1, forcing
+    const StepSched *sched;          // if non-null, ct/ct_next/ft come from sched[slot] instead (graph replay)
+    int slot;
     int write_diag;
     unsigned long long *stamps;      // diagnostic builds only (EBM_STAMPS), else nullptr
 };

@@ -395,7 +395,9 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
     const Params &p = *a.p;
     const double *const gX = a.geom + G_X * a.gstride;
     double *const st = a.state + (size_t)col * (size_t)a.pitch;         // wave-uniform
-    const double f = a.fcol ? a.ft + a.fcol[col] : a.ft;
+    const double ct = a.sched ? a.sched[a.slot].ct : a.ct;              // per-step scalars (scalar loads)
+    const double ft = a.sched ? a.sched[a.slot].ft : a.ft;
+    const double f = a.fcol ? ft + a.fcol[col] : ft;
     const double Tm = p.Tm;
     EBM_STAMP(0);
 
@@ -475,7 +477,7 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
         // the active set, computed once
 #pragma unroll
         for (int i = 0; i < C; ++i) {
-            const double S = p.S0 - p.S1 * xk[i] * a.ct - p.S2 * (xk[i] * xk[i]);   // :11
+            const double S = p.S0 - p.S1 * xk[i] * ct - p.S2 * (xk[i] * xk[i]);     // :11
             const double rm = i > 0 ? r[i > 0 ? i - 1 : 0] : rl;
             const double rp = i < C - 1 ? r[i < C - 1 ? i + 1 : i] : rr;
             const double dif = __builtin_fma(tup[i], rp - r[i], tlo[i] * (rm - r[i]));
@@ -555,7 +557,7 @@ __global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_ker
             const double tbm = i > 0 ? tb[i > 0 ? i - 1 : 0] : tbl;
             const double tbp = i < C - 1 ? tb[i < C - 1 ? i + 1 : i] : tbr;
             const double xp = i < C - 1 ? xk[i < C - 1 ? i + 1 : i] : xr;
-            const double S = p.S0 - p.S1 * xk[i] * a.ct - p.S2 * (xk[i] * xk[i]);
+            const double S = p.S0 - p.S1 * xk[i] * ct - p.S2 * (xk[i] * xk[i]);
             double dif;
             if (GRID == 0) {
                 dif = diffusion_add<0>(0.0, p.D, k, nlat, g0[GRID == 0 ? i : 0], g1[GRID == 0 ? i : 0],
@@ -630,7 +632,10 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) classic_step_kernel(co
     const Params &p = *a.p;
     double *const st = a.state + (size_t)col * (size_t)a.pitch;          // wave-uniform
     const double *const ge = a.geom;
-    const double f = a.fcol ? a.ft + a.fcol[col] : a.ft;
+    const double ct = a.sched ? a.sched[a.slot].ct : a.ct;
+    const double ct_next = a.sched ? a.sched[a.slot].ct_next : a.ct_next;
+    const double ft = a.sched ? a.sched[a.slot].ft : a.ft;
+    const double f = a.fcol ? ft + a.fcol[col] : ft;
 
     double E[C], Tg[C], xk[C], aw[C], Sb[C], kd[C];
     load_chunk<C>(st + C_E * a.fstride, k0, E);
@@ -644,8 +649,8 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) classic_step_kernel(co
     for (int i = 0; i < C; ++i) {
         const bool valid = (int)k0 + i < nlat;
         double Ek = E[i];
-        const double S_i = Sb[i] - (p.S1 * a.ct) * xk[i];                          // :23-24
-        const double S_ip1 = Sb[i] - (p.S1 * a.ct_next) * xk[i];
+        const double S_i = Sb[i] - (p.S1 * ct) * xk[i];                            // :23-24
+        const double S_ip1 = Sb[i] - (p.S1 * ct_next) * xk[i];
         const double alpha = bool_mul(aw[i], Ek > 0.0) + bool_mul(p.ai, Ek < 0.0); // :47
         const double Cc = alpha * S_i + p.cg_tau * Tg[i] - p.A + f;                // :48
         const double T0 = Cc / (p.M - p.kLf / Ek);                                 // :50

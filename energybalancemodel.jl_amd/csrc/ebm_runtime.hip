@@ -46,6 +46,10 @@ struct ebm_ctx {
     double *fcol = nullptr;
     unsigned long long *stamps = nullptr;          // diagnostic builds only
     int num_cus = 0;
+    // hipGraph replay for launch-bound shapes (small grids): kGraphSteps step kernels per replay
+    ebm::StepSched *sched_dev = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool use_graph = false;
     std::vector<double> ttab;                      // cos(2*pi*t_i), host copy
     unsigned long long *counters = nullptr;        // device, kCounterShards x 2
     unsigned short *amask = nullptr;               // MIZ warm-start active set, ncol x threads
@@ -177,6 +181,37 @@ ebm::StepArgs base_args(const ebm_ctx *h) {
     return a;
 }
 
+constexpr int kGraphSteps = 64;
+
+hipError_t launch_step(ebm_ctx *h, const ebm::StepArgs &a) {
+    return (h->model == EBM_MODEL_MIZ) ? ebm::launch_miz_step(a, h->grid, h->cfg, h->stream)
+                                       : ebm::launch_classic_step(a, h->ncol, h->cfg, h->stream);
+}
+
+// Capture kGraphSteps step kernels (node i reads sched_dev[i]) into a graph, once per handle.
+int build_graph(ebm_ctx *h) {
+    HIPCHK(hipMalloc(&h->sched_dev, sizeof(ebm::StepSched) * kGraphSteps));
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < kGraphSteps && e == hipSuccess; ++i) {
+        ebm::StepArgs a = base_args(h);
+        a.sched = h->sched_dev;
+        a.slot = i;
+        a.write_diag = 0;
+        e = launch_step(h, a);
+    }
+    hipError_t e2 = hipStreamEndCapture(h->stream, &graph);
+    if (e != hipSuccess || e2 != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return fail(EBM_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+    }
+    e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+    return EBM_OK;
+}
+
 int do_step(ebm_ctx *h, double ct, double ct_next, double f, int write_diag) {
     ebm::StepArgs a = base_args(h);
     a.state = h->state; a.fstride = h->fstride; a.geom = h->geom; a.gstride = h->gstride;
@@ -184,9 +219,7 @@ int do_step(ebm_ctx *h, double ct, double ct_next, double f, int write_diag) {
     a.pitch = (int)h->pitch; a.nlat = h->nlat; a.ncol = h->ncol;
     a.ct = ct; a.ct_next = ct_next; a.ft = f; a.write_diag = write_diag;
     a.stamps = h->stamps;
-    hipError_t e = (h->model == EBM_MODEL_MIZ)
-                       ? ebm::launch_miz_step(a, h->grid, h->cfg, h->stream)
-                       : ebm::launch_classic_step(a, h->ncol, h->cfg, h->stream);
+    hipError_t e = launch_step(h, a);
     if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     h->n_steps += 1;
     h->n_launches += 1;
@@ -226,6 +259,9 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, device));
         h->num_cus = prop.multiProcessorCount;
+        // a step of fewer than ~256K cells is launch-bound: replay graphs in ebm_run (EBM_GRAPH=0/1 overrides)
+        const char *gv = std::getenv("EBM_GRAPH");
+        h->use_graph = gv ? std::atoi(gv) != 0 : ((long long)nlat * ncol <= 262144);
     }
     h->pitch = (long long)cfg.threads * cfg.cells;     // >= nlat; padding cells stay zero
     fill_params(h->p, params, dt);
@@ -265,6 +301,8 @@ int ebm_destroy(ebm_handle_t h) {
     if (h->geom) (void)hipFree(h->geom);
     if (h->state) (void)hipFree(h->state);
     if (h->p_dev) (void)hipFree(h->p_dev);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->sched_dev) (void)hipFree(h->sched_dev);
     if (h->amask) (void)hipFree(h->amask);
     if (h->fcol) (void)hipFree(h->fcol);
     if (h->counters) (void)hipFree(h->counters);
@@ -340,7 +378,32 @@ int ebm_run(ebm_handle_t h, long long first_step, int nsteps, const double *f_st
     if (h->ttab.empty()) return fail(EBM_ERR_ARG, "ebm_run: call ebm_set_time_table first");
     HIPCHK(hipSetDevice(h->device));
     const long long nt = (long long)h->ttab.size();
-    for (int s = 0; s < nsteps; ++s) {
+    int s = 0;
+    if (h->use_graph && nsteps >= 2 * kGraphSteps) {
+        // launch-bound shapes: replay a captured graph of kGraphSteps launches (still one launch
+        // per step); the per-step scalars travel through a small device table
+        if (!h->graph_exec) {
+            int rc = build_graph(h);
+            if (rc) return rc;
+        }
+        std::vector<ebm::StepSched> sched(kGraphSteps);
+        const int last_graph_step = nsteps - (diag_last ? 1 : 0);     // a diagnostic last step is launched directly
+        for (; s + kGraphSteps <= last_graph_step; s += kGraphSteps) {
+            for (int i = 0; i < kGraphSteps; ++i) {
+                const long long ti = (first_step + s + i) % nt;
+                sched[i].ct = h->ttab[ti];
+                sched[i].ct_next = h->ttab[(ti + 1) % nt];
+                sched[i].ft = f_steps ? f_steps[s + i] : 0.0;
+            }
+            // pageable source: the copy is staged before the call returns, so `sched` can be refilled
+            HIPCHK(hipMemcpyAsync(h->sched_dev, sched.data(), sizeof(ebm::StepSched) * kGraphSteps,
+                                  hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
+            h->n_steps += kGraphSteps;
+            h->n_launches += kGraphSteps;
+        }
+    }
+    for (; s < nsteps; ++s) {
         const long long ti = (first_step + s) % nt;
         const double f = f_steps ? f_steps[s] : 0.0;
         int rc = do_step(h, h->ttab[ti], h->ttab[(ti + 1) % nt], f, diag_last && s == nsteps - 1);

@@ -211,6 +211,31 @@ def test_miz_sizes_vs_oracle(pkg, coracle, kind, nlat, ncol, nt, spin, nsteps):
     assert cnt["solves"] == ocnt[0] and cnt["cap_hits"] == 0     # same active-set iteration path
 
 
+@pytest.mark.parametrize("model", ["MIZ", "Classic"])
+def test_graph_replay_equals_direct_launches(pkg, monkeypatch, model):
+    """ebm_run replays a captured hipGraph of 64 step launches on launch-bound shapes (per-step
+    scalars through a device table).  Same launches, same arguments: bitwise identical state, with
+    a varying forcing and a run length that exercises replay + remainder + diagnostic last step."""
+    g = load_golden("classic_identity_180_2000.npz")
+    st = pkg.SpaceTime("identity" if model == "Classic" else "sin", 180, 2000, 1)
+    par = pkg.default_parameters(model)
+    nsteps = 64 * 3 + 17
+    f_steps = 0.3 * np.sin(np.arange(nsteps) / 7.0)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("EBM_GRAPH", mode)
+        with make_engine(pkg, model, st, par, 2) as eng:
+            if model == "Classic":
+                eng.set_state(dict(E=np.tile(g["s0_E"], (2, 1)), Tg=np.tile(g["s0_Tg"], (2, 1))))
+            eng.set_column_forcing(np.array([0.0, 1.0]))
+            eng.set_time_table(st.t)
+            eng.run(1990, nsteps, f_steps, True)          # wraps around the year end
+            out[mode] = eng.get_state()
+            assert eng.counters()["steps"] == nsteps
+    for k in out["0"]:
+        assert np.array_equal(out["0"][k], out["1"][k], equal_nan=True), k
+
+
 def test_alternative_geometry_512x8(pkg, coracle, monkeypatch):
     """EBM_CELLS_PER_THREAD=8 selects 512 threads x 8 cells for 2048 < nlat <= 4096 (a tuning knob:
     slower on MI355X, kept as a tested alternative).  Same results as the default geometry."""
