@@ -384,7 +384,7 @@ struct MizCfg {
 
 // TT: workgroup size known at compile time (LDS offsets become immediates), 0 = use blockDim.x.
 template <int C, int GRID, bool DIAG, int TT>
-__global__ void __launch_bounds__(TT ? TT : MizCfg<C>::kMaxThreads) miz_step_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) miz_step_kernel(const StepArgs a) {
     constexpr bool STASH = MizCfg<C>::kStash;
     extern __shared__ double smem[];
     const int T = TT ? TT : (int)blockDim.x, t = threadIdx.x, col = blockIdx.x;
@@ -758,7 +758,9 @@ hipError_t prepare_kernels(const LaunchCfg &cfg) {
     };
     hipError_t e = hipSuccess;
     if (cfg.cells == 4) {
+        // only the shapes that can exceed the 64 KiB default need the attribute
         if ((e = for_each_miz<4, 0>(set)) != hipSuccess) return e;
+        if ((e = for_each_miz<4, 512>(set)) != hipSuccess) return e;
         if ((e = for_each_miz<4, 1024>(set)) != hipSuccess) return e;
         e = set(reinterpret_cast<const void *>(classic_step_kernel<4>));
     } else if (cfg.cells == 8) {
@@ -788,6 +790,11 @@ hipError_t launch_miz_step(const StepArgs &a, int grid_kind, const LaunchCfg &cf
     const size_t lds = cfg.lds_bytes;
     if (cfg.cells == 4) {
         if (cfg.threads == 1024) launch_miz_ct<4, 1024>(a, grid, block, grid_kind, lds, s);
+        else if (cfg.threads == 512) launch_miz_ct<4, 512>(a, grid, block, grid_kind, lds, s);
+        else if (cfg.threads == 384) launch_miz_ct<4, 384>(a, grid, block, grid_kind, lds, s);
+        else if (cfg.threads == 256) launch_miz_ct<4, 256>(a, grid, block, grid_kind, lds, s);
+        else if (cfg.threads == 128) launch_miz_ct<4, 128>(a, grid, block, grid_kind, lds, s);
+        else if (cfg.threads == 64) launch_miz_ct<4, 64>(a, grid, block, grid_kind, lds, s);
         else launch_miz_ct<4, 0>(a, grid, block, grid_kind, lds, s);
     } else if (cfg.cells == 8) {
         if (cfg.threads == 512) launch_miz_ct<8, 512>(a, grid, block, grid_kind, lds, s);
