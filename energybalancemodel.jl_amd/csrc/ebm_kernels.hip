@@ -653,18 +653,18 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) classic_step_kernel(co
         const double S_ip1 = Sb[i] - (p.S1 * ct_next) * xk[i];
         const double alpha = bool_mul(aw[i], Ek > 0.0) + bool_mul(p.ai, Ek < 0.0); // :47
         const double Cc = alpha * S_i + p.cg_tau * Tg[i] - p.A + f;                // :48
-        const double T0 = Cc / (p.M - p.kLf / Ek);                                 // :50
-        const double Tk = bool_mul(Ek / p.cw, Ek >= 0.0) + bool_mul(bool_mul(T0, Ek < 0.0), T0 < 0.0);
+        const double T0 = ieee_div(Cc, p.M - ieee_div(p.kLf, Ek));                                 // :50
+        const double Tk = bool_mul(ieee_div(Ek, p.cw), Ek >= 0.0) + bool_mul(bool_mul(T0, Ek < 0.0), T0 < 0.0);
         Ek = Ek + p.dt * (Cc - p.M * Tk + p.Fb);                                   // :53
-        const double den = p.M - p.kLf / Ek;
-        const double q = bool_mul(bool_mul(p.dc / den, T0 < 0.0), Ek < 0.0);       // :56
-        const double rhs = Tg[i] + p.dt_tau * (bool_mul(Ek / p.cw, Ek >= 0.0) +
-                           bool_mul(bool_mul((p.ai * S_ip1 - p.A + f) / den, T0 < 0.0), Ek < 0.0));
+        const double den = p.M - ieee_div(p.kLf, Ek);
+        const double q = bool_mul(bool_mul(ieee_div(p.dc, den), T0 < 0.0), Ek < 0.0);       // :56
+        const double rhs = Tg[i] + p.dt_tau * (bool_mul(ieee_div(Ek, p.cw), Ek >= 0.0) +
+                           bool_mul(bool_mul(ieee_div(p.ai * S_ip1 - p.A + f, den), T0 < 0.0), Ek < 0.0));
         b[i] = valid ? kd[i] - q : 1.0;
         d[i] = valid ? rhs : 0.0;
         E[i] = Ek;
         oT[i] = Tk;
-        oh[i] = bool_mul(-Ek / p.Lf, Ek < 0.0);                                    // :65
+        oh[i] = bool_mul(ieee_div(-Ek, p.Lf), Ek < 0.0);                                    // :65
     }
     store_chunk<C>(st + C_E * a.fstride, E, k0, nlat);
     if (a.write_diag) {

@@ -407,6 +407,28 @@ def test_device_division_is_ieee(pkg):
     assert same[moderate].all(), int((~same[moderate]).sum())
 
 
+def test_classic_on_sin_grid_uses_uniform_operator(pkg, coracle):
+    """get_statics builds kappa from get_diffop(nx) whatever the grid type (src/classic.jl:21): on
+    SpaceTime{sin} the classic model still diffuses with the uniform-x operator while x enters the
+    insolation and co-albedo.  Same here."""
+    st = pkg.SpaceTime("sin", 200, 2000, 1)
+    par = pkg.default_parameters("Classic")
+    Ts = 30.0 - 45.0 * st.x ** 2
+    state = dict(E=np.where(Ts >= 0, par["cw"] * Ts, par["Lf"] * Ts / 7.5)[None].copy(), Tg=Ts[None].copy())
+    ct = ctab(pkg, st)
+    nsteps = 60
+    with make_engine(pkg, "Classic", st, par, 1) as eng:
+        eng.set_state(state)
+        eng.set_time_table(st.t)
+        eng.run(0, nsteps)
+        got = eng.get_state(("E", "Tg", "T", "h"))
+    idx = np.arange(nsteps)
+    out = coracle.classic_run(st.x, dict(par), st.dt, ct[idx], ct[(idx + 1) % st.nt], np.zeros(nsteps), None, state)
+    ref = dict(state)
+    ref.update(out)
+    check_all(got, ref, TOL_SHORT, names=("E", "Tg", "T", "h"), what="classic on sin grid")
+
+
 # ---- the reference's operator surface ------------------------------------------------------------
 def test_step_bang_surface(pkg):
     """step!(Val(:MIZ), t, f, vars, st, par) called directly, 10 times from the zero state
