@@ -160,6 +160,11 @@ __device__ __forceinline__ void halo_exchange(double *E0, double *E1, int t, int
 //  4. Back-substitute inside the chunk.
 // P0/P1: 3T doubles each.  On entry P1 must be free and P0 free after the first barrier inside;
 // on exit other threads may still be reading P0/P1 (callers put a barrier before reuse).
+#ifndef EBM_SECOND_LEVEL_ROWS
+#define EBM_SECOND_LEVEL_ROWS 4
+#endif
+constexpr int kSecondLevelRows = EBM_SECOND_LEVEL_ROWS;
+
 template <int C>
 __device__ __forceinline__ void partition_solve(const double (&a)[C], const double (&b)[C],
                                                 const double (&c)[C], const double (&d)[C],
@@ -208,6 +213,7 @@ __device__ __forceinline__ void partition_solve(const double (&a)[C], const doub
         pc = RC * rinv;
         pd = RD * rinv;
     }
+#ifdef EBM_PCR_FLAT
     double *src = P0, *dst = P1;
     src[t] = pa;
     src[T + t] = pc;
@@ -237,6 +243,117 @@ __device__ __forceinline__ void partition_solve(const double (&a)[C], const doub
     }
     const double Lraw = src[2 * T + (t > 0 ? t - 1 : 0)];
     const double L = t > 0 ? Lraw : 0.0;
+#else
+    // Second partition level: the T interface rows (unit diagonal) are handed to the first
+    // G = T/R threads, R consecutive rows each, which repeat steps 1-3 on them; only the
+    // G second-level interface rows go through parallel cyclic reduction.  Waves beyond the first
+    // G threads only take part in the barriers.  Rows are exchanged through LDS transposed
+    // (row q of group g at [q*G + g]) so that both sides access consecutive words.
+    constexpr int R = kSecondLevelRows;
+    const int G = T / R;
+    const bool lvl2 = t < G;
+    {
+        const int q = t % R, g = t / R;
+        P0[q * G + g] = pa;
+        P0[T + q * G + g] = pc;
+        P0[2 * T + q * G + g] = pd;
+    }
+    __syncthreads();
+    double a2[R], c2[R], d2[R], cq[R - 1], dq[R - 1], lq[R - 1];
+    double *U = P1, *S0 = P1 + 3 * G, *S1 = P1 + 6 * G;
+    if (lvl2) {
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            a2[i] = P0[i * G + t];
+            c2[i] = P0[T + i * G + t];
+            d2[i] = P0[2 * T + i * G + t];
+        }
+        cq[0] = c2[0];
+        dq[0] = d2[0];
+        lq[0] = -a2[0];
+#pragma unroll
+        for (int i = 1; i < R - 1; ++i) {
+            const double w = fast_rcp(__builtin_fma(-a2[i], cq[i - 1], 1.0));
+            cq[i] = c2[i] * w;
+            dq[i] = __builtin_fma(-a2[i], dq[i - 1], d2[i]) * w;
+            lq[i] = -(a2[i] * lq[i - 1]) * w;
+        }
+        double u2 = dq[R - 2], v2 = lq[R - 2], w2 = -cq[R - 2];
+#pragma unroll
+        for (int i = R - 3; i >= 0; --i) {
+            u2 = __builtin_fma(-cq[i], u2, dq[i]);
+            v2 = __builtin_fma(-cq[i], v2, lq[i]);
+            w2 = -cq[i] * w2;
+        }
+        U[t] = u2;
+        U[G + t] = v2;
+        U[2 * G + t] = w2;
+    }
+    __syncthreads();
+    double qa = 0.0, qc = 0.0, qd = 0.0;
+    if (lvl2) {
+        const bool nxt = t + 1 < G;
+        const int gn = nxt ? t + 1 : t;
+        double un2 = U[gn], vn2 = U[G + gn], wn2 = U[2 * G + gn];
+        un2 = nxt ? un2 : 0.0;
+        vn2 = nxt ? vn2 : 0.0;
+        wn2 = nxt ? wn2 : 0.0;
+        const double ae = a2[R - 1], ce = c2[R - 1], de = d2[R - 1];
+        const double RA = ae * lq[R - 2];
+        const double RB = __builtin_fma(ce, vn2, __builtin_fma(-ae, cq[R - 2], 1.0));
+        const double RC = ce * wn2;
+        const double RD = __builtin_fma(-ce, un2, __builtin_fma(-ae, dq[R - 2], de));
+        const double rinv = fast_rcp(RB);
+        qa = RA * rinv;
+        qc = RC * rinv;
+        qd = RD * rinv;
+        S0[t] = qa;
+        S0[G + t] = qc;
+        S0[2 * G + t] = qd;
+    }
+    __syncthreads();
+    // Out-of-range neighbours need no special case: by induction qa == 0 exactly whenever row
+    // t-s does not exist (and qc == 0 when t+s does not), so reading a clamped, finite row and
+    // multiplying by that zero contributes nothing.
+    double *src = S0, *dst = S1;
+    for (int s = 1; s < G; s <<= 1) {
+        if (lvl2) {
+            const int im = t - s >= 0 ? t - s : t, ip = t + s < G ? t + s : t;
+            const double am = src[im], cm = src[G + im], dm = src[2 * G + im];
+            const double ap = src[ip], cn = src[G + ip], dn = src[2 * G + ip];
+            const double r = fast_rcp(__builtin_fma(-qc, ap, __builtin_fma(-qa, cm, 1.0)));
+            const double nqd = __builtin_fma(-qc, dn, __builtin_fma(-qa, dm, qd)) * r;
+            const double nqa = -(qa * am) * r;
+            const double nqc = -(qc * cn) * r;
+            qa = nqa;
+            qc = nqc;
+            qd = nqd;
+            dst[t] = qa;
+            dst[G + t] = qc;
+            dst[2 * G + t] = qd;
+        }
+        __syncthreads();
+        double *tmp = src;
+        src = dst;
+        dst = tmp;
+    }
+    if (lvl2) {
+        const double L2raw = src[2 * G + (t > 0 ? t - 1 : 0)];
+        const double L2 = t > 0 ? L2raw : 0.0;
+        double y = qd;
+        P0[(R - 1) * G + t] = y;   // the level-1 rows in P0 were consumed before the barriers above
+#pragma unroll
+        for (int i = R - 2; i >= 0; --i) {
+            y = __builtin_fma(-cq[i], y, __builtin_fma(lq[i], L2, dq[i]));
+            P0[i * G + t] = y;
+        }
+    }
+    __syncthreads();
+    pd = P0[(t % R) * G + t / R];
+    const int tm = t > 0 ? t - 1 : 0;
+    const double Lraw = P0[(tm % R) * G + tm / R];
+    const double L = t > 0 ? Lraw : 0.0;
+#endif
     x[C - 1] = pd;
 #pragma unroll
     for (int i = C - 2; i >= 0; --i) x[i] = __builtin_fma(-cp[i], x[i + 1], __builtin_fma(lp[i], L, dp[i]));
