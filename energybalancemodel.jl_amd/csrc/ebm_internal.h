@@ -58,6 +58,7 @@ struct StepArgs {
     const StepSched *sched;          // if non-null, ct/ct_next/ft come from sched[slot] instead (graph replay)
     int slot;
     int write_diag;
+    int prefetch;                    // MIZ: L2 prefetch distance in columns (0 = off)
     unsigned long long *stamps;      // diagnostic builds only (EBM_STAMPS), else nullptr
 };
 

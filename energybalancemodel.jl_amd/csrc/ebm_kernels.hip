@@ -58,6 +58,11 @@ typedef double ebm_dvec2 __attribute__((ext_vector_type(2)));
 #define EBM_STAMP(n) do {} while (0)
 #endif
 
+// The parameter block is never written by a kernel: read it through the constant address space so
+// that every access is a scalar load, also after the kernel's own global stores (through a plain
+// pointer hipcc falls back to per-lane vector loads once the kernel has stored anything).
+typedef const __attribute__((address_space(4))) Params ConstParams;
+
 // ---- Julia IEEE semantics ----------------------------------------------------------------
 __device__ __forceinline__ double jl_min(double x, double y) {
     // Base.min(::Float64, ::Float64): NaN-propagating, -0.0 < +0.0
@@ -364,7 +369,7 @@ struct MizCellOut {
     double Ei, Ew, h, D, phi, n, E, T, Ti, Tw;
 };
 
-__device__ __forceinline__ MizCellOut miz_cell_update(const Params &p, double f, double S, double xk,
+__device__ __forceinline__ MizCellOut miz_cell_update(ConstParams &p, double f, double S, double xk,
                                                      double dif, double tb, double Ei, double Ew,
                                                      double hk, double Dk, double ph, double Tw,
                                                      double Ti) {
@@ -509,7 +514,7 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) miz_step_kernel(const 
     const unsigned k0 = (unsigned)t * C;
     double *P0 = smem, *P1 = smem + 3 * T;
     double *sEw = smem + 6 * T + t, *sh = sEw + C * T, *sTw = sh + C * T;
-    const Params &p = *a.p;
+    ConstParams &p = *reinterpret_cast<ConstParams *>(reinterpret_cast<uintptr_t>(a.p));
     const double *const gX = a.geom + G_X * a.gstride;
     double *const st = a.state + (size_t)col * (size_t)a.pitch;         // wave-uniform
     const double ct = a.sched ? a.sched[a.slot].ct : a.ct;              // per-step scalars (scalar loads)
@@ -691,6 +696,26 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) miz_step_kernel(const 
             const double tw = STASH ? sTw[i * T] : Twreg[STASH ? 0 : i];
             o[q] = miz_cell_update(p, f, S, xk[i], dif, tb[i], q ? Ei2.y : Ei2.x, Ewk, hk, q ? Dk2.y : Dk2.x,
                                    ph[i], tw, xs[i]);
+            if (WHOLE && i == C - 2) {
+                // L2 prefetch for the workgroup that follows this one on the XCD (column + a.prefetch):
+                // one 4-byte LDS-DMA load per 32-B sector of its phase-A inputs, issued once this
+                // thread's own loads have all been consumed and hidden under the last cell's
+                // arithmetic.  The data lands in stash words of cell C-2 that this wave has just
+                // finished with and is never read.
+                // (hipcc waits vmcnt(0) at the first use of any earlier load's result while an LDS-DMA is
+                // in flight: retire the one load not consumed yet before issuing it)
+                asm volatile("" ::"v"(xr), "v"(o[q].Ei), "v"(o[q].Ew), "v"(o[q].h), "v"(o[q].D), "v"(o[q].phi));
+                __builtin_amdgcn_sched_barrier(0);
+                if (a.prefetch > 0 && col + a.prefetch < a.ncol) {
+                    const double *nxt = a.state + (size_t)(col + a.prefetch) * (size_t)a.pitch +
+                                        ((unsigned)(t >> 6) * 256u + (unsigned)(t & 63) * 4u);
+                    auto *sink = (__attribute__((address_space(3))) void *)(smem + 6 * T + (C - 2) * T + (t & ~63));
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nxt + S_Ew * a.fstride), sink, 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nxt + S_phi * a.fstride), sink, 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(nxt + S_h * a.fstride), sink, 4, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         const unsigned kp = k0 + 2 * j;
@@ -710,6 +735,9 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) miz_step_kernel(const 
             sh[0] = v0 ? o[0].D : 0.0;  sh[T] = v1 ? o[1].D : 0.0;
             sTw[0] = v0 ? o[0].phi : 0.0;  sTw[T] = v1 ? o[1].phi : 0.0;
         } else if (WHOLE) {
+            // the LDS-DMA prefetch must have landed before this wave can end (its LDS is released
+            // with the workgroup); it was issued a whole cell update ago
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #define EBM_PUT4(slot, member, w0, w1)                                                             \
             {                                                                                      \
                 double2 a_, b_;                                                                    \
@@ -746,7 +774,7 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) classic_step_kernel(co
     const int nlat = a.nlat;
     const unsigned k0 = (unsigned)t * C;
     double *P0 = smem, *P1 = smem + 3 * T;
-    const Params &p = *a.p;
+    ConstParams &p = *reinterpret_cast<ConstParams *>(reinterpret_cast<uintptr_t>(a.p));
     double *const st = a.state + (size_t)col * (size_t)a.pitch;          // wave-uniform
     const double *const ge = a.geom;
     const double ct = a.sched ? a.sched[a.slot].ct : a.ct;

@@ -46,6 +46,7 @@ struct ebm_ctx {
     double *fcol = nullptr;
     unsigned long long *stamps = nullptr;          // diagnostic builds only
     int num_cus = 0;
+    int prefetch = 0;                 // L2 prefetch distance of the MIZ kernel, columns (0 = off)
     // hipGraph replay for launch-bound shapes (small grids): kGraphSteps step kernels per replay
     ebm::StepSched *sched_dev = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -178,6 +179,7 @@ ebm::StepArgs base_args(const ebm_ctx *h) {
     a.fcol = h->fcol; a.p = h->p_dev; a.counters = h->counters; a.amask = h->amask;
     a.pitch = (int)h->pitch; a.nlat = h->nlat; a.ncol = h->ncol;
     a.stamps = h->stamps;
+    a.prefetch = h->prefetch;
     return a;
 }
 
@@ -262,6 +264,16 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
         // a step of fewer than ~256K cells is launch-bound: replay graphs in ebm_run (EBM_GRAPH=0/1 overrides)
         const char *gv = std::getenv("EBM_GRAPH");
         h->use_graph = gv ? std::atoi(gv) != 0 : ((long long)nlat * ncol <= 262144);
+    }
+    {
+        // One workgroup per CU (a long meridian fills the CU's LDS): nothing overlaps the input
+        // loads of a workgroup, so each workgroup prefetches into L2 the inputs of the one that
+        // follows it on its XCD, num_cus columns ahead (workgroups go round-robin over the XCDs
+        // and in order within one).  EBM_PREFETCH_COLS overrides (0 = off).
+        const char *pv = std::getenv("EBM_PREFETCH_COLS");
+        const bool one_wg_per_cu = cfg.lds_bytes > 80 * 1024;
+        h->prefetch = pv ? std::atoi(pv) : (one_wg_per_cu && ncol > h->num_cus ? h->num_cus : 0);
+        if (h->prefetch < 0) h->prefetch = 0;
     }
     h->pitch = (long long)cfg.threads * cfg.cells;     // >= nlat; padding cells stay zero
     fill_params(h->p, params, dt);
