@@ -236,6 +236,31 @@ def test_graph_replay_equals_direct_launches(pkg, monkeypatch, model):
         assert np.array_equal(out["0"][k], out["1"][k], equal_nan=True), k
 
 
+def test_l2_prefetch_does_not_change_results(pkg, monkeypatch):
+    """Long meridians (one workgroup per CU): every workgroup prefetches into L2 the inputs of the
+    workgroup `EBM_PREFETCH_COLS` columns ahead (default: the CU count) with LDS-DMA loads whose
+    data is discarded.  Off, default and an odd distance: bitwise identical state."""
+    nlat, ncol, nt, nsteps = 4096, 520, 1048576, 12
+    st = pkg.SpaceTime("sin", nlat, nt, 1)
+    par = pkg.default_parameters("MIZ")
+    fcol = 2.0 * np.sin(np.arange(ncol) / 9.0)
+    out = {}
+    for mode in ("0", None, "7"):
+        if mode is None:
+            monkeypatch.delenv("EBM_PREFETCH_COLS", raising=False)
+        else:
+            monkeypatch.setenv("EBM_PREFETCH_COLS", mode)
+        with make_engine(pkg, "MIZ", st, par, ncol) as eng:
+            eng.set_column_forcing(fcol)
+            eng.set_time_table(st.t)
+            eng.run(0, nsteps, None, True)
+            out[mode] = eng.get_state()
+    for mode in (None, "7"):
+        for k in out["0"]:
+            assert np.array_equal(out["0"][k], out[mode][k], equal_nan=True), (mode, k)
+    assert np.any(out["0"]["Ew"] != 0.0)
+
+
 def test_alternative_geometry_512x8(pkg, coracle, monkeypatch):
     """EBM_CELLS_PER_THREAD=8 selects 512 threads x 8 cells for 2048 < nlat <= 4096 (a tuning knob:
     slower on MI355X, kept as a tested alternative).  Same results as the default geometry."""
