@@ -112,7 +112,12 @@ def main():
     st = pkg.SpaceTime(kind, nlat, nt, 1)
     par = pkg.default_parameters(model)
     lon = np.arange(ncol) + rank * ncol                      # this rank's block of columns
-    fcol = 0.5 * np.sin(2.0 * np.pi * lon / ncol)
+    if args.workload == "miz_1024x512x32":
+        # BASELINE configs[4] / SURVEY 8(d) cfg5: 32 members of 512 meridians per GPU, member m of 256
+        # forced by the constant f_m = -2 + 4 m/255 W/m2
+        fcol = -2.0 + 4.0 * ((lon // 512) % 256) / 255.0
+    else:
+        fcol = 0.5 * np.sin(2.0 * np.pi * lon / ncol)
     eng = pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval),
                      st.dt, ncol, device=device)
     if model == "Classic":
@@ -179,7 +184,8 @@ def main():
         "config": {
             "workload": f"{args.workload}: {model} model, {nlat} lat x {ncol} meridians per GPU, "
                         f"{kind} grid, nt={nt}, {args.spinup} spin-up steps from zero state, "
-                        f"f[lon]=0.5*sin(2*pi*lon/nlon)",
+                        + ("f[member]=-2+4*member/255" if args.workload == "miz_1024x512x32"
+                           else "f[lon]=0.5*sin(2*pi*lon/nlon)"),
             "steps_per_launch": 1,
             "ice_covered_fraction": ice_fraction,
             "mean_tridiagonal_solves_per_column_step": (cnt["solves"] / (args.steps * ncol)) if model == "MIZ" else 1.0,

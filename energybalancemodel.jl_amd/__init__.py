@@ -10,6 +10,8 @@ from .infrastructure import (  # noqa: F401
     default_parameters, step_, integrate, reset_step_state, classic_time_index,
     MIZ_SOLVARS, CLASSIC_SOLVARS,
 )
-from .ensemble import EnsembleRun, shard_columns, gather_columns, hemispheric_mean  # noqa: F401
+from .ensemble import (  # noqa: F401
+    EnsembleRun, shard_columns, gather_columns, broadcast_inputs, hemispheric_mean,
+)
 
 Vec = "numpy.ndarray[float64]"  # the reference's Vec = Vector{Float64} (src/infrastructure.jl:13)

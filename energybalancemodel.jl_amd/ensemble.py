@@ -71,6 +71,35 @@ class EnsembleRun:
         self.engine.close()
 
 
+def broadcast_inputs(arrays: dict | None, dist=None, device=None, src: int = 0) -> dict:
+    """Broadcast the run's small inputs — ``st.x``, the parameter vector, the per-step forcing
+    table, the per-column forcing offsets — from rank ``src`` to every rank (I/O only, a few KB;
+    SURVEY §8(e)).  ``arrays`` maps names to fp64 arrays on ``src`` and is ignored elsewhere;
+    every rank returns the same dict.  With dist=None (single process) returns ``arrays``."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in (arrays or {}).items()}
+    import torch
+    rank = dist.get_rank()
+    meta = [None]
+    if rank == src:
+        arrays = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in arrays.items()}
+        meta = [[(k, v.shape) for k, v in arrays.items()]]
+    dist.broadcast_object_list(meta, src=src)                 # names and shapes (host side)
+    total = sum(int(np.prod(shape)) for _, shape in meta[0])
+    flat = np.concatenate([arrays[k].ravel() for k, _ in meta[0]]) if rank == src else np.empty(total)
+    t = torch.from_numpy(flat)
+    if device is not None:
+        t = t.to(device)
+    dist.broadcast(t, src=src)                                # one message for all payloads
+    flat = t.cpu().numpy()
+    out, pos = {}, 0
+    for k, shape in meta[0]:
+        n = int(np.prod(shape))
+        out[k] = flat[pos:pos + n].reshape(shape).copy()
+        pos += n
+    return out
+
+
 def gather_columns(local: np.ndarray, ncol_total: int, dist=None, device=None) -> np.ndarray | None:
     """Gather per-column data ([ncol_local, ...]) from all ranks to rank 0 (I/O only).
 

@@ -1,5 +1,6 @@
 """World-size-2 test of the multi-GPU path's plumbing on CPU (gloo): block-sharding of the
-columns, global column indexing of the per-column forcing, and the I/O gather.  The per-rank
+columns, the I/O broadcast of the inputs from rank 0, global column indexing of the per-column
+forcing, and the I/O gather.  The per-rank
 compute is done by the oracle here (there is no GPU), which is exactly what the HIP path is
 checked against in the -m gpu tests; columns are independent, so no collective is involved
 in the time loop itself."""
@@ -25,7 +26,15 @@ WORKER = textwrap.dedent("""
     ncol, nlat, nsteps = 11, 96, 25
     st = pkg.SpaceTime("sin", nlat, 4000, 1)
     par = pkg.default_parameters("MIZ")
-    fcol_all = -2.0 + 4.0 * np.arange(ncol) / (ncol - 1)          # cfg5-style member forcing
+    # rank 0 owns the inputs; every other rank receives them (I/O broadcast, SURVEY 8(e))
+    mine = None
+    if rank == 0:
+        mine = dict(x=st.x, fcol=-2.0 + 4.0 * np.arange(ncol) / (ncol - 1),    # cfg5-style member forcing
+                    params=np.array([par[k] for k in sorted(par)]), ftab=np.zeros((2, nsteps)))
+    got = pkg.broadcast_inputs(mine, dist)
+    assert np.array_equal(got["x"], st.x) and got["ftab"].shape == (2, nsteps)
+    assert np.array_equal(got["params"], np.array([par[k] for k in sorted(par)]))
+    fcol_all = got["fcol"]
     sl = pkg.shard_columns(ncol, ws, rank)
     n_loc = sl.stop - sl.start
     state = {{k: np.zeros((n_loc, nlat)) for k in ("Ei", "Ew", "h", "D", "phi", "T0")}}

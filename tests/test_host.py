@@ -151,3 +151,11 @@ def test_shard_columns(pkg):
 def test_hemispheric_mean(pkg):
     x = np.linspace(0, 1, 101)
     assert pkg.hemispheric_mean(2 * x, x) == pytest.approx(1.0, rel=1e-12)   # src/utilities.jl:397-403
+
+
+def test_broadcast_inputs_single_process(pkg):
+    """Without a process group the I/O broadcast is the identity (fp64, contiguous copies)."""
+    x = np.linspace(0.0, 1.0, 7)
+    got = pkg.broadcast_inputs(dict(x=x[::2], f=[1, 2, 3]))
+    assert np.array_equal(got["x"], x[::2]) and got["x"].flags["C_CONTIGUOUS"]
+    assert got["f"].dtype == np.float64
