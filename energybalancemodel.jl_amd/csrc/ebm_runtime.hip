@@ -485,10 +485,13 @@ int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int la
         const long long ti = (tinx - 1) % nt + 1;
         const long long year = (tinx - 1) / nt + 1;                // ceil(st.T[tinx])
         const double f = f_steps ? f_steps[tinx - 1] : 0.0;
-        int rc = do_step(h, h->ttab[ti - 1], h->ttab[ti % nt], f, 1);
-        if (rc) { cleanup(); return rc; }
         // savesol!, src/infrastructure.jl:549-591: annual-mean sums and raw snapshot in one launch
         const bool want_raw = stage && (!lastonly || tinx > total - nt);
+        // the diagnostic fields are only written on steps whose values are saved (or on the last one)
+        const bool want_season = (ti == winter_inx && winter) || (ti == summer_inx && summer);
+        const int diag = (sums || want_raw || want_season || tinx == total) ? 1 : 0;
+        int rc = do_step(h, h->ttab[ti - 1], h->ttab[ti % nt], f, diag);
+        if (rc) { cleanup(); return rc; }
         if (sums || want_raw) {
             ebm::SaveArgs sa{};
             sa.state = h->state; sa.fstride = h->fstride;

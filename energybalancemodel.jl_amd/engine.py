@@ -119,15 +119,17 @@ class Engine:
               "ebm_run")
 
     def integrate(self, nt, dur, f_steps, lastonly, winter_inx, summer_inx, names,
-                  want_raw=True, want_seasonal=True):
-        """ebm_integrate: returns dict(raw, winter, summer, avg), each [nvars, n, ncol, nlat]."""
+                  want_raw=True, want_seasonal=True, want_avg=True):
+        """ebm_integrate: returns dict(raw, winter, summer, avg), each [nvars, n, ncol, nlat].
+        Outputs that are not wanted are None; with neither raw nor avg the diagnostic fields are
+        only written on the steps whose snapshot is taken."""
         nv = len(names)
         fields = (C.c_int * nv)(*[FIELD[n] for n in names])
         nraw = nt if lastonly else nt * dur
         f = None if f_steps is None else as_f64(f_steps, (nt * dur,))
         raw = np.empty((nv, nraw, self.ncol, self.nlat)) if want_raw else None
         mk = (lambda: np.full((nv, dur, self.ncol, self.nlat), np.nan)) if want_seasonal else (lambda: None)
-        winter, summer, avg = mk(), mk(), mk()
+        winter, summer, avg = mk(), mk(), (mk() if want_avg else None)
         check(self.lib.ebm_integrate(self._h, nt, dur, dptr(f), int(lastonly), int(winter_inx),
                                      int(summer_inx), nv, fields, dptr(raw), dptr(winter),
                                      dptr(summer), dptr(avg)), "ebm_integrate")

@@ -507,6 +507,28 @@ def test_integrate_surface_matches_oracle(pkg, oracle, lastonly):
     assert sols.counters["steps"] == 1000
 
 
+def test_integrate_seasonal_snapshots_only(pkg):
+    """ebm_integrate with only the winter/summer snapshots requested runs the steps in between
+    without the diagnostic stores; snapshots and final state are bitwise those of the full run."""
+    st = pkg.SpaceTime("sin", 180, 2000, 1)
+    par = pkg.default_parameters("MIZ")
+    names = ("Ei", "Ew", "h", "D", "phi", "Tw", "Ti", "n", "E", "T")
+    out, final = {}, {}
+    for mode in ("full", "seasonal"):
+        with make_engine(pkg, "MIZ", st, par, 2) as eng:
+            eng.set_column_forcing(np.array([0.0, 1.5]))
+            eng.set_time_table(st.t)
+            out[mode] = eng.integrate(st.nt, 1, None, True, st.winter.inx, st.summer.inx, names,
+                                      want_raw=(mode == "full"), want_avg=(mode == "full"))
+            final[mode] = eng.get_state()
+    assert out["seasonal"]["raw"] is None and out["seasonal"]["avg"] is None
+    for k in ("winter", "summer"):
+        assert np.array_equal(out["full"][k], out["seasonal"][k], equal_nan=True), k
+    for k in final["full"]:
+        assert np.array_equal(final["full"][k], final["seasonal"][k], equal_nan=True), k
+    assert np.array_equal(out["full"]["raw"][:, st.winter.inx - 1], out["full"]["winter"][:, 0], equal_nan=True)
+
+
 def test_integrate_classic_surface(pkg, oracle):
     g = load_golden("classic_identity_180_2000.npz")
     st = pkg.SpaceTime("identity", 180, 2000, 1)
