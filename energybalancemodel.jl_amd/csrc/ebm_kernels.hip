@@ -54,8 +54,19 @@ typedef double ebm_dvec2 __attribute__((ext_vector_type(2)));
         __builtin_amdgcn_sched_barrier(0);                                             \
         if (threadIdx.x == 0 && a.stamps) a.stamps[(size_t)blockIdx.x * 16 + (n)] = t_; \
     } while (0)
+// per-wave variant: lane 0 of every wave records into a.stamps[ncol*16 + (col*16 + wave)*8 + n]
+#define EBM_STAMPW(n)                                                                  \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        unsigned long long t_;                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");      \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        if ((threadIdx.x & 63) == 0 && a.stamps)                                       \
+            a.stamps[(size_t)a.ncol * 16 + ((size_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (n)] = t_; \
+    } while (0)
 #else
 #define EBM_STAMP(n) do {} while (0)
+#define EBM_STAMPW(n) do {} while (0)
 #endif
 
 // The parameter block is never written by a kernel: read it through the constant address space so
@@ -522,6 +533,7 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) miz_step_kernel(const 
     const double f = a.fcol ? ft + a.fcol[col] : ft;
     const double Tm = p.Tm;
     EBM_STAMP(0);
+    EBM_STAMPW(0);                                        // per wave: first instruction
 
     // ---------------- phase A: loads, water temperature, T0-system coefficients ----------
     // Only phi and the right-hand side stay in registers across the solve; everything else the
@@ -592,6 +604,7 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) miz_step_kernel(const 
             r[i] = (1.0 - ph[i]) * (tw - Tm);
         }
         EBM_STAMP(1);
+        EBM_STAMPW(1);                                    // per wave: inputs arrived
         double rl, rr;
         halo_exchange(P0, P0 + T, t, T, r[0], r[C - 1], rl, rr);
         EBM_STAMP(2);
@@ -629,6 +642,7 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) miz_step_kernel(const 
     }
     *wmask = (unsigned short)smask;                       // new warm start, src/miz.jl:64
     EBM_STAMP(6);
+    EBM_STAMPW(2);                                        // per wave: phase D starts
 
     // ---------------- phase D: fluxes and state update ---------------------------------------
     double xk[C];
@@ -657,6 +671,7 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) miz_step_kernel(const 
     double tbl, tbr;
     halo_exchange(P0, P0 + T, t, T, tb[0], tb[C - 1], tbl, tbr);
     EBM_STAMP(7);
+    EBM_STAMPW(3);                                        // per wave: Tbar halo done
     // Whole-line stores.  A lane owns 8*C contiguous bytes of every field; written pair by pair,
     // each 128-B line would reach L2 in two halves ~10^4 cycles apart and be written back to HBM
     // twice.  For C = 4 the first pair's new prognostics are parked in LDS words that are dead by
@@ -737,6 +752,7 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) miz_step_kernel(const 
         } else if (WHOLE) {
             // the LDS-DMA prefetch must have landed before this wave can end (its LDS is released
             // with the workgroup); it was issued a whole cell update ago
+            EBM_STAMPW(5);                                // per wave: arithmetic done, before the stores
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #define EBM_PUT4(slot, member, w0, w1)                                                             \
             {                                                                                      \
@@ -762,8 +778,10 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) miz_step_kernel(const 
         }
 #undef EBM_PUT
         if (j < 2) EBM_STAMP(8 + j);
+        if (j == 0) EBM_STAMPW(4);                        // per wave: first pair done
     }
     EBM_STAMP(15);
+    EBM_STAMPW(6);                                        // per wave: stores issued
 }
 
 // ---- classic (WE15) step, src/classic.jl:37-71 ------------------------------------------------

@@ -581,12 +581,13 @@ int ebm_timer_stop(ebm_handle_t h, float *elapsed_ms) {
 }
 
 #ifdef EBM_STAMPS
-// Diagnostic build only: allocate / fetch the per-workgroup phase stamps (ncol x 16).
+// Diagnostic build only: allocate / fetch the phase stamps: per workgroup (ncol x 16), then per wave
+// (ncol x 16 waves x 8).
 int ebm_debug_stamps(ebm_handle_t h, unsigned long long *host) {
     if (!h) return fail(EBM_ERR_ARG, "ebm_debug_stamps: null handle");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    const size_t nb = sizeof(unsigned long long) * 16 * (size_t)h->ncol;
+    const size_t nb = sizeof(unsigned long long) * (16 + 128) * (size_t)h->ncol;
     if (!h->stamps) {
         HIPCHK(hipMalloc(&h->stamps, nb));
         HIPCHK(hipMemset(h->stamps, 0, nb));

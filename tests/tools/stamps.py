@@ -20,9 +20,9 @@ lib.ebm_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 lib.ebm_debug_stamps(eng._h, None)
 eng.run(300, 3, None, False); eng.sync()
 nwg = eng.launch_info()["workgroups"]
-buf = np.zeros((ncol, 16), dtype=np.uint64)
+buf = np.zeros(ncol * (16 + 128), dtype=np.uint64)     # per-workgroup stamps, then per-wave ones (wave_stamps.py)
 lib.ebm_debug_stamps(eng._h, buf.ctypes.data_as(C.POINTER(C.c_ulonglong)))
-s = buf.astype(np.int64)[:nwg]
+s = buf[:ncol * 16].reshape(ncol, 16).astype(np.int64)[:nwg]
 names = ["start", "A:loads+Tw", "A:r halo", "A:rhs+sync", "B:g halo+rows", "B:partition solve", "B:check+sync",
          "D:tb+halo", "D:pair0", "D:pair1", "-", "-", "-", "-", "-", "end"]
 order = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 15]
