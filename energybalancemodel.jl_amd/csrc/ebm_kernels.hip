@@ -901,7 +901,7 @@ LaunchCfg choose_launch(int nlat, bool prefer_c8) {
     return cfg;
 }
 
-// All instantiations of the MIZ kernel for one C: grid kind x diagnostics x {generic T, fixed T}.
+// All instantiations of the MIZ kernel for one (C, T): grid kind x diagnostics.
 template <int C, int TT, typename F>
 static hipError_t for_each_miz(F &&fn) {
     hipError_t e;
@@ -910,31 +910,6 @@ static hipError_t for_each_miz(F &&fn) {
     if ((e = fn(reinterpret_cast<const void *>(miz_step_kernel<C, 0, true, TT>))) != hipSuccess) return e;
     if ((e = fn(reinterpret_cast<const void *>(miz_step_kernel<C, 1, true, TT>))) != hipSuccess) return e;
     return hipSuccess;
-}
-
-// Dynamic LDS above the 64 KiB default must be requested per kernel.
-hipError_t prepare_kernels(const LaunchCfg &cfg) {
-    if (cfg.lds_bytes <= 64 * 1024) return hipSuccess;
-    const int bytes = (int)cfg.lds_bytes;
-    auto set = [bytes](const void *fn) {
-        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    };
-    hipError_t e = hipSuccess;
-    if (cfg.cells == 4) {
-        // only the shapes that can exceed the 64 KiB default need the attribute
-        if ((e = for_each_miz<4, 0>(set)) != hipSuccess) return e;
-        if ((e = for_each_miz<4, 512>(set)) != hipSuccess) return e;
-        if ((e = for_each_miz<4, 1024>(set)) != hipSuccess) return e;
-        e = set(reinterpret_cast<const void *>(classic_step_kernel<4>));
-    } else if (cfg.cells == 8) {
-        if ((e = for_each_miz<8, 0>(set)) != hipSuccess) return e;
-        if ((e = for_each_miz<8, 512>(set)) != hipSuccess) return e;
-        e = set(reinterpret_cast<const void *>(classic_step_kernel<8>));
-    } else {
-        if ((e = for_each_miz<16, 0>(set)) != hipSuccess) return e;
-        e = set(reinterpret_cast<const void *>(classic_step_kernel<16>));
-    }
-    return e;
 }
 
 template <int C, int TT>
@@ -948,23 +923,53 @@ static void launch_miz_ct(const StepArgs &a, dim3 grid, dim3 block, int grid_kin
     }
 }
 
+// The workgroup sizes compiled with T as a constant (LDS offsets become immediates, fewer
+// registers); any other size runs the generic TT = 0 kernel.
+template <int C, int... TTs>
+struct MizShapes {
+    template <typename F>
+    static hipError_t for_each(F &&fn) {
+        hipError_t e = for_each_miz<C, 0>(fn);
+        (void)((e == hipSuccess && (e = for_each_miz<C, TTs>(fn)) == hipSuccess) && ...);
+        return e;
+    }
+    static void launch(const StepArgs &a, dim3 grid, dim3 block, int grid_kind, size_t lds, hipStream_t s) {
+        const int threads = (int)block.x;
+        const bool fixed = ((threads == TTs ? (launch_miz_ct<C, TTs>(a, grid, block, grid_kind, lds, s), true) : false) || ...);
+        if (!fixed) launch_miz_ct<C, 0>(a, grid, block, grid_kind, lds, s);
+    }
+};
+using Miz4 = MizShapes<4, 64, 128, 192, 256, 320, 384, 448, 512, 576, 640, 704, 768, 832, 896, 960, 1024>;
+using Miz8 = MizShapes<8, 512>;
+using Miz16 = MizShapes<16>;
+
+// Dynamic LDS above the 64 KiB default must be requested per kernel.
+hipError_t prepare_kernels(const LaunchCfg &cfg) {
+    if (cfg.lds_bytes <= 64 * 1024) return hipSuccess;
+    const int bytes = (int)cfg.lds_bytes;
+    auto set = [bytes](const void *fn) {
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    };
+    hipError_t e = hipSuccess;
+    if (cfg.cells == 4) {
+        if ((e = Miz4::for_each(set)) != hipSuccess) return e;
+        e = set(reinterpret_cast<const void *>(classic_step_kernel<4>));
+    } else if (cfg.cells == 8) {
+        if ((e = Miz8::for_each(set)) != hipSuccess) return e;
+        e = set(reinterpret_cast<const void *>(classic_step_kernel<8>));
+    } else {
+        if ((e = Miz16::for_each(set)) != hipSuccess) return e;
+        e = set(reinterpret_cast<const void *>(classic_step_kernel<16>));
+    }
+    return e;
+}
+
 hipError_t launch_miz_step(const StepArgs &a, int grid_kind, const LaunchCfg &cfg, hipStream_t s) {
     dim3 grid(a.ncol), block(cfg.threads);
     const size_t lds = cfg.lds_bytes;
-    if (cfg.cells == 4) {
-        if (cfg.threads == 1024) launch_miz_ct<4, 1024>(a, grid, block, grid_kind, lds, s);
-        else if (cfg.threads == 512) launch_miz_ct<4, 512>(a, grid, block, grid_kind, lds, s);
-        else if (cfg.threads == 384) launch_miz_ct<4, 384>(a, grid, block, grid_kind, lds, s);
-        else if (cfg.threads == 256) launch_miz_ct<4, 256>(a, grid, block, grid_kind, lds, s);
-        else if (cfg.threads == 128) launch_miz_ct<4, 128>(a, grid, block, grid_kind, lds, s);
-        else if (cfg.threads == 64) launch_miz_ct<4, 64>(a, grid, block, grid_kind, lds, s);
-        else launch_miz_ct<4, 0>(a, grid, block, grid_kind, lds, s);
-    } else if (cfg.cells == 8) {
-        if (cfg.threads == 512) launch_miz_ct<8, 512>(a, grid, block, grid_kind, lds, s);
-        else launch_miz_ct<8, 0>(a, grid, block, grid_kind, lds, s);
-    } else {
-        launch_miz_ct<16, 0>(a, grid, block, grid_kind, lds, s);
-    }
+    if (cfg.cells == 4) Miz4::launch(a, grid, block, grid_kind, lds, s);
+    else if (cfg.cells == 8) Miz8::launch(a, grid, block, grid_kind, lds, s);
+    else Miz16::launch(a, grid, block, grid_kind, lds, s);
     return hipGetLastError();
 }
 
