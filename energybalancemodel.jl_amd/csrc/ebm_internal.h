@@ -41,7 +41,7 @@ enum GeomTable { G_X = 0, G_0, G_1, G_2, G_3, G_4, G_LO, G_DI, G_UP, G_KSUB, G_K
 // Per-step scalars of a graph-replayed step: kernel node `slot` of the replayed graph reads entry
 // `slot` of a small device table that the host refills before every replay.
 struct StepSched {
-    double ct, ct_next, ft;
+    double ct, ct_next, ft, tyear;
 };
 
 struct StepArgs {
@@ -50,11 +50,13 @@ struct StepArgs {
     const double *geom;
     long long gstride;
     const double *fcol;              // per-column forcing offset or nullptr
+    const double *fsched;            // per-column Forcing schedules [ncol][kSchedWords] or nullptr
     const Params *p;                 // device memory
     unsigned long long *counters;    // 64 shards x {solves, cap hits} (MIZ)
     unsigned short *amask;           // MIZ warm start as an active set: [ncol][threads], bit i <=> T0 < Tm in cell i of the thread
     int pitch, nlat, ncol;
     double ct, ct_next, ft;          // cos(2 pi t) [MIZ / classic column i], classic column i+1, forcing
+    double tyear;                    // model time of the step in years (st.T[tinx]), for the schedules
     const StepSched *sched;          // if non-null, ct/ct_next/ft come from sched[slot] instead (graph replay)
     int slot;
     int write_diag;
@@ -69,6 +71,7 @@ struct LaunchCfg {
 };
 
 constexpr int kCounterShards = 64;
+constexpr int kSchedWords = 9;     // base, peak, cool, rate up, rate down, domain[1..4]
 constexpr int kMaxNewton = 50;
 
 LaunchCfg choose_launch(int nlat, bool prefer_c8);

@@ -129,6 +129,25 @@ __device__ __forceinline__ double fast_rcp(double x) {
     return r;
 }
 
+// Forcing of one column at one step: the step's scalar, plus the column's constant offset, plus the
+// column's own Forcing{false} schedule (src/infrastructure.jl:208-241) evaluated at the model time
+// T of the step exactly as the reference does (:294-307): hold, ramp up, hold, ramp down, hold.
+__device__ __forceinline__ double column_forcing(const StepArgs &a, int col, double ft, double tyear) {
+    double f = a.fcol ? ft + a.fcol[col] : ft;
+    if (a.fsched) {
+        const double *w = a.fsched + (size_t)kSchedWords * col;     // wave-uniform: scalar loads
+        const double base = w[0], peak = w[1], cool = w[2], up = w[3], down = w[4];
+        const double d1 = w[5], d2 = w[6], d3 = w[7], d4 = w[8];
+        double v = cool;
+        if (tyear < d1) v = base;
+        else if (tyear < d2) v = base + up * (tyear - d1);
+        else if (tyear < d3) v = peak;
+        else if (tyear < d4) v = peak + down * (tyear - d3);
+        f = f + v;
+    }
+    return f;
+}
+
 // ---- chunk loads / stores: 8*C contiguous bytes per lane, 16-byte accesses ------------------
 // `f` is a wave-uniform base (kept in SGPRs), `k0` the lane's first cell: the access compiles to
 // the saddr + voffset form, so no per-lane 64-bit pointers are kept alive.
@@ -530,7 +549,7 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) miz_step_kernel(const 
     double *const st = a.state + (size_t)col * (size_t)a.pitch;         // wave-uniform
     const double ct = a.sched ? a.sched[a.slot].ct : a.ct;              // per-step scalars (scalar loads)
     const double ft = a.sched ? a.sched[a.slot].ft : a.ft;
-    const double f = a.fcol ? ft + a.fcol[col] : ft;
+    const double f = column_forcing(a, col, ft, a.sched ? a.sched[a.slot].tyear : a.tyear);
     const double Tm = p.Tm;
     EBM_STAMP(0);
     EBM_STAMPW(0);                                        // per wave: first instruction
@@ -798,7 +817,7 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) classic_step_kernel(co
     const double ct = a.sched ? a.sched[a.slot].ct : a.ct;
     const double ct_next = a.sched ? a.sched[a.slot].ct_next : a.ct_next;
     const double ft = a.sched ? a.sched[a.slot].ft : a.ft;
-    const double f = a.fcol ? ft + a.fcol[col] : ft;
+    const double f = column_forcing(a, col, ft, a.sched ? a.sched[a.slot].tyear : a.tyear);
 
     double E[C], Tg[C], xk[C], aw[C], Sb[C], kd[C];
     load_chunk<C>(st + C_E * a.fstride, k0, E);

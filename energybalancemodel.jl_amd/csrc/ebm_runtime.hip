@@ -44,6 +44,8 @@ struct ebm_ctx {
     int nslots = 0;
     double *field[EBM_F_COUNT] = {nullptr};        // views into the slab (null: not in this model)
     double *fcol = nullptr;
+    double *fsched = nullptr;                      // per-column Forcing schedules
+    long long clock = 0;                           // global index of the next step (model time of ebm_step)
     unsigned long long *stamps = nullptr;          // diagnostic builds only
     int num_cus = 0;
     int prefetch = 0;                 // L2 prefetch distance of the MIZ kernel, columns (0 = off)
@@ -176,7 +178,7 @@ void fill_params(ebm::Params &p, const double *v, double dt) {
 ebm::StepArgs base_args(const ebm_ctx *h) {
     ebm::StepArgs a{};
     a.state = h->state; a.fstride = h->fstride; a.geom = h->geom; a.gstride = h->gstride;
-    a.fcol = h->fcol; a.p = h->p_dev; a.counters = h->counters; a.amask = h->amask;
+    a.fcol = h->fcol; a.fsched = h->fsched; a.p = h->p_dev; a.counters = h->counters; a.amask = h->amask;
     a.pitch = (int)h->pitch; a.nlat = h->nlat; a.ncol = h->ncol;
     a.stamps = h->stamps;
     a.prefetch = h->prefetch;
@@ -214,17 +216,33 @@ int build_graph(ebm_ctx *h) {
     return EBM_OK;
 }
 
-int do_step(ebm_ctx *h, double ct, double ct_next, double f, int write_diag) {
+// model time of 0-based global step `step`: st.T[step+1] = (2 step + 1)/(2 nt), correctly rounded
+double year_time(const ebm_ctx *h, long long step) {
+    const double nt = (double)h->ttab.size();
+    return nt > 0.0 ? (double)(2 * step + 1) / (2.0 * nt) : 0.0;
+}
+
+// drop the captured graph: its kernel nodes hold the argument values of the time of capture
+void invalidate_graph(ebm_ctx *h) {
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    h->graph_exec = nullptr;
+    if (h->sched_dev) (void)hipFree(h->sched_dev);
+    h->sched_dev = nullptr;
+}
+
+int do_step(ebm_ctx *h, double ct, double ct_next, double f, int write_diag, long long step) {
     ebm::StepArgs a = base_args(h);
     a.state = h->state; a.fstride = h->fstride; a.geom = h->geom; a.gstride = h->gstride;
     a.fcol = h->fcol; a.p = h->p_dev; a.counters = h->counters;
     a.pitch = (int)h->pitch; a.nlat = h->nlat; a.ncol = h->ncol;
     a.ct = ct; a.ct_next = ct_next; a.ft = f; a.write_diag = write_diag;
+    a.tyear = year_time(h, step);
     a.stamps = h->stamps;
     hipError_t e = launch_step(h, a);
     if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     h->n_steps += 1;
     h->n_launches += 1;
+    h->clock = step + 1;
     return EBM_OK;
 }
 
@@ -317,6 +335,7 @@ int ebm_destroy(ebm_handle_t h) {
     if (h->sched_dev) (void)hipFree(h->sched_dev);
     if (h->amask) (void)hipFree(h->amask);
     if (h->fcol) (void)hipFree(h->fcol);
+    if (h->fsched) (void)hipFree(h->fsched);
     if (h->counters) (void)hipFree(h->counters);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -364,12 +383,38 @@ int ebm_set_column_forcing(ebm_handle_t h, const double *fcol) {
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (!fcol) {
-        if (h->fcol) HIPCHK(hipFree(h->fcol));
+        if (h->fcol) { HIPCHK(hipFree(h->fcol)); invalidate_graph(h); }
         h->fcol = nullptr;
         return EBM_OK;
     }
-    if (!h->fcol) HIPCHK(hipMalloc(&h->fcol, sizeof(double) * h->ncol));
+    if (!h->fcol) { HIPCHK(hipMalloc(&h->fcol, sizeof(double) * h->ncol)); invalidate_graph(h); }
     HIPCHK(hipMemcpy(h->fcol, fcol, sizeof(double) * h->ncol, hipMemcpyHostToDevice));
+    return EBM_OK;
+}
+
+int ebm_set_column_schedule(ebm_handle_t h, const double *sched) {
+    if (!h) return fail(EBM_ERR_ARG, "ebm_set_column_schedule: null handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const size_t nb = sizeof(double) * ebm::kSchedWords * (size_t)h->ncol;
+    if (!sched) {
+        if (h->fsched) { HIPCHK(hipFree(h->fsched)); invalidate_graph(h); }
+        h->fsched = nullptr;
+        return EBM_OK;
+    }
+    for (int c = 0; c < h->ncol; ++c) {
+        const double *w = sched + (size_t)ebm::kSchedWords * c;
+        if (!(w[5] <= w[6] && w[6] <= w[7] && w[7] <= w[8]))
+            return fail(EBM_ERR_ARG, "ebm_set_column_schedule: breakpoints must be non-decreasing");
+    }
+    if (!h->fsched) { HIPCHK(hipMalloc(&h->fsched, nb)); invalidate_graph(h); }
+    HIPCHK(hipMemcpy(h->fsched, sched, nb, hipMemcpyHostToDevice));
+    return EBM_OK;
+}
+
+int ebm_set_step_clock(ebm_handle_t h, long long step) {
+    if (!h || step < 0) return fail(EBM_ERR_ARG, "ebm_set_step_clock: bad argument");
+    h->clock = step;
     return EBM_OK;
 }
 
@@ -382,7 +427,8 @@ int ebm_set_time_table(ebm_handle_t h, int nt, const double *cos2pit) {
 int ebm_step(ebm_handle_t h, double cos2pit, double cos2pit_next, double f, int write_diag) {
     if (!h) return fail(EBM_ERR_ARG, "ebm_step: null handle");
     HIPCHK(hipSetDevice(h->device));
-    return do_step(h, cos2pit, cos2pit_next, f, write_diag);
+    if (h->fsched && h->ttab.empty()) return fail(EBM_ERR_ARG, "ebm_step: column schedules need the time table (ebm_set_time_table)");
+    return do_step(h, cos2pit, cos2pit_next, f, write_diag, h->clock);
 }
 
 int ebm_run(ebm_handle_t h, long long first_step, int nsteps, const double *f_steps, int diag_last) {
@@ -406,6 +452,7 @@ int ebm_run(ebm_handle_t h, long long first_step, int nsteps, const double *f_st
                 sched[i].ct = h->ttab[ti];
                 sched[i].ct_next = h->ttab[(ti + 1) % nt];
                 sched[i].ft = f_steps ? f_steps[s + i] : 0.0;
+                sched[i].tyear = year_time(h, first_step + s + i);
             }
             // pageable source: the copy is staged before the call returns, so `sched` can be refilled
             HIPCHK(hipMemcpyAsync(h->sched_dev, sched.data(), sizeof(ebm::StepSched) * kGraphSteps,
@@ -413,12 +460,13 @@ int ebm_run(ebm_handle_t h, long long first_step, int nsteps, const double *f_st
             HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
             h->n_steps += kGraphSteps;
             h->n_launches += kGraphSteps;
+            h->clock = first_step + s + kGraphSteps;
         }
     }
     for (; s < nsteps; ++s) {
         const long long ti = (first_step + s) % nt;
         const double f = f_steps ? f_steps[s] : 0.0;
-        int rc = do_step(h, h->ttab[ti], h->ttab[(ti + 1) % nt], f, diag_last && s == nsteps - 1);
+        int rc = do_step(h, h->ttab[ti], h->ttab[(ti + 1) % nt], f, diag_last && s == nsteps - 1, first_step + s);
         if (rc) return rc;
     }
     return EBM_OK;
@@ -490,7 +538,7 @@ int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int la
         // the diagnostic fields are only written on steps whose values are saved (or on the last one)
         const bool want_season = (ti == winter_inx && winter) || (ti == summer_inx && summer);
         const int diag = (sums || want_raw || want_season || tinx == total) ? 1 : 0;
-        int rc = do_step(h, h->ttab[ti - 1], h->ttab[ti % nt], f, diag);
+        int rc = do_step(h, h->ttab[ti - 1], h->ttab[ti % nt], f, diag, tinx - 1);
         if (rc) { cleanup(); return rc; }
         if (sums || want_raw) {
             ebm::SaveArgs sa{};

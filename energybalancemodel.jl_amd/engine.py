@@ -20,6 +20,16 @@ CLASSIC_PROGNOSTIC = ("E", "Tg")
 CLASSIC_DIAGNOSTIC = ("T", "h")
 
 
+def schedule_words(forcing):
+    """The 9 words of one column's schedule (include/ebm_hip.h): base, peak, cool, the two rates
+    and Forcing.domain[1:]; a constant Forcing is a schedule that never leaves its first hold."""
+    if forcing.constant:
+        return [forcing.base, forcing.base, forcing.base, 0.0, 0.0, np.inf, np.inf, np.inf, np.inf]
+    d = forcing.domain
+    return [forcing.base, forcing.peak, forcing.cool, float(forcing.rates[0]), float(forcing.rates[1]),
+            float(d[1]), float(d[2]), float(d[3]), float(d[4])]
+
+
 def cos2pit(t: float) -> float:
     """cos(2.0*pi*t) exactly as the reference writes it (src/miz.jl:11, src/classic.jl:24)."""
     return math.cos(2.0 * math.pi * t)
@@ -101,6 +111,20 @@ class Engine:
     def set_column_forcing(self, fcol):
         a = None if fcol is None else as_f64(fcol, (self.ncol,))
         check(self.lib.ebm_set_column_forcing(self._h, dptr(a)), "ebm_set_column_forcing")
+
+    def set_column_schedules(self, forcings):
+        """Per-column Forcing schedules evaluated on the device (ebm_set_column_schedule):
+        ``forcings`` is a sequence of ``ncol`` Forcing objects, or None to clear."""
+        if forcings is None:
+            check(self.lib.ebm_set_column_schedule(self._h, None), "ebm_set_column_schedule")
+            return
+        if len(forcings) != self.ncol:
+            raise ValueError(f"expected {self.ncol} Forcing objects, got {len(forcings)}")
+        a = np.array([schedule_words(f) for f in forcings], dtype=np.float64)
+        check(self.lib.ebm_set_column_schedule(self._h, dptr(a)), "ebm_set_column_schedule")
+
+    def set_step_clock(self, step: int):
+        check(self.lib.ebm_set_step_clock(self._h, int(step)), "ebm_set_step_clock")
 
     def set_time_table(self, t_in_year):
         """t_in_year = st.t; uploads cos(2.0*pi*t_i)."""

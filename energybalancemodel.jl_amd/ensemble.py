@@ -35,13 +35,17 @@ class EnsembleRun:
     """``ncol`` independent columns of one model on one GPU (this rank's shard).
 
     ``init`` maps prognostic names to [ncol, nlat] arrays (or [nlat], broadcast to all
-    columns); ``fcol`` is the per-column forcing offset."""
+    columns); ``fcol`` is the per-column forcing offset; ``forcings`` a sequence of one Forcing
+    per column, evaluated on the device at every step (hysteresis ensembles: every member its own
+    ramp)."""
 
-    def __init__(self, model, st, par, init, fcol=None, device=0):
+    def __init__(self, model, st, par, init, fcol=None, device=0, forcings=None):
         first = np.asarray(next(iter(init.values())))
         self.ncol = 1 if first.ndim == 1 else first.shape[0]
         if fcol is not None:
             self.ncol = len(fcol)
+        if forcings is not None:
+            self.ncol = len(forcings)
         self.st = st
         self.engine = Engine(model, st.grid_kind, st.x, param_vector(par, default_parval), st.dt,
                              self.ncol, device)
@@ -53,6 +57,8 @@ class EnsembleRun:
         if fcol is not None:
             self.engine.set_column_forcing(fcol)
         self.engine.set_time_table(st.t)
+        if forcings is not None:
+            self.engine.set_column_schedules(forcings)
         self.step_index = 0
 
     def run(self, nsteps, forcing=None, diag_last=True):

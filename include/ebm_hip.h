@@ -95,6 +95,17 @@ int ebm_field_device_ptr(ebm_handle_t h, int field, double **dptr, long long *pi
  * NULL clears it).  This is how ensemble members / longitudes get perturbed forcings — the
  * reference has a single scalar `f` per step (src/infrastructure.jl:631). */
 int ebm_set_column_forcing(ebm_handle_t h, const double *fcol);
+/* Per-column forcing SCHEDULES: column c is additionally forced by its own Forcing{false}
+ * (src/infrastructure.jl:208-241), evaluated on the device at the model time T of every step as
+ * the reference's call operator does (:294-307):
+ *     T < d1: base;  T < d2: base + up*(T - d1);  T < d3: peak;  T < d4: peak + down*(T - d3);  else cool
+ * sched[ncol][9] = {base, peak, cool, up, down, d1, d2, d3, d4} (d = Forcing.domain[2..5]); NULL
+ * clears.  T of 0-based global step n is st.T[n+1] = (2n+1)/(2 nt): ebm_run takes n from
+ * first_step, ebm_integrate starts at n = 0, ebm_step uses and advances the handle's step clock
+ * (ebm_set_step_clock).  Needs the time table (its length is nt).  The three contributions add:
+ * forcing = f + fcol[c] + schedule_c(T). */
+int ebm_set_column_schedule(ebm_handle_t h, const double *sched);
+int ebm_set_step_clock(ebm_handle_t h, long long step);
 /* Table of cos(2.0*pi*st.t[i]), i = 1..nt (src/miz.jl:11, src/classic.jl:24), needed by
  * ebm_run/ebm_integrate.  Computed by the caller so that host and device agree bit for bit. */
 int ebm_set_time_table(ebm_handle_t h, int nt, const double *cos2pit);

@@ -128,4 +128,24 @@ function integrate(model::Symbol, st::SpaceTime{F}, forcing::Forcing{C}, par::Co
     return hip_integrate(model, st, forcing, par, init; kw...)
 end
 
+"""
+    set_member_forcings!(h, forcings::Vector{<:Forcing})
+
+One `Forcing` per column (ensemble member), evaluated on the device at `st.T[tinx]` of every
+step with the reference's own call operator (`src/infrastructure.jl:294-307`).
+"""
+function set_member_forcings!(h::Handle, forcings::AbstractVector)
+    words = Matrix{Float64}(undef, 9, length(forcings))           # column-major == C [ncol][9]
+    for (c, f) in enumerate(forcings)
+        if f isa Forcing{true}
+            words[:, c] = [f.base, f.base, f.base, 0.0, 0.0, Inf, Inf, Inf, Inf]
+        else
+            words[:, c] = [f.base, f.peak, f.cool, f.rates[1], f.rates[2],
+                           Float64(f.domain[2]), Float64(f.domain[3]), Float64(f.domain[4]), Float64(f.domain[5])]
+        end
+    end
+    check(ccall((:ebm_set_column_schedule, libebm), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), h.ptr, words),
+          "ebm_set_column_schedule")
+end
+
 end # module EBMHip
