@@ -95,6 +95,9 @@ hipError_t launch_savesol(const SaveArgs &a, hipStream_t s);
 // active set from the T0 field (after ebm_set_field(T0))
 hipError_t launch_mask_from_t0(const StepArgs &a, int ncol, const LaunchCfg &cfg, hipStream_t s);
 hipError_t launch_divide(const double *a, const double *b, double *q, int n, hipStream_t s);
+// out[col] = hemispheric_mean(field[col], x), src/utilities.jl:397-403 (sequential sum, bit-exact)
+hipError_t launch_hemispheric_mean(const double *field, const double *x, int pitch, int nlat, int ncol, double *out,
+                                   hipStream_t s);
 // dst[i] = sum[i]/nt, sum[i] = 0
 hipError_t launch_finish_mean(double *dst, double *sum, double nt, size_t n, hipStream_t s);
 

@@ -895,6 +895,24 @@ __global__ void savesol_kernel(const SaveArgs a) {
         }
     }
 }
+// hemispheric_mean (src/utilities.jl:397-403) of one field, one workgroup per column:
+//   int = 0; for i in 1:nx-1: int += (vec[i]+vec[i+1]) * (x[i+1]-x[i]) / 2.0
+// The terms are formed in parallel (elementwise, exact order of operations); the accumulation is
+// the reference's strictly sequential left-to-right sum, done by one lane out of LDS, so the
+// result is bit-identical to the reference's loop.
+__global__ void hemispheric_mean_kernel(const double *__restrict__ field, const double *__restrict__ x,
+                                        int pitch, int nlat, double *__restrict__ out) {
+    extern __shared__ double terms[];
+    const double *v = field + (size_t)blockIdx.x * pitch;
+    for (int i = threadIdx.x; i < nlat - 1; i += blockDim.x)
+        terms[i] = ieee_div((v[i] + v[i + 1]) * (x[i + 1] - x[i]), 2.0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double acc = 0.0;
+        for (int i = 0; i < nlat - 1; ++i) acc = acc + terms[i];
+        out[blockIdx.x] = acc;
+    }
+}
 __global__ void finish_mean_kernel(double *__restrict__ dst, double *__restrict__ sum, double nt, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         dst[i] = sum[i] / nt;
@@ -1010,6 +1028,11 @@ hipError_t launch_savesol(const SaveArgs &a, hipStream_t s) {
     int blocks = (int)((ncell + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     savesol_kernel<<<blocks, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+hipError_t launch_hemispheric_mean(const double *field, const double *x, int pitch, int nlat, int ncol, double *out,
+                                   hipStream_t s) {
+    hemispheric_mean_kernel<<<ncol, 256, sizeof(double) * (size_t)nlat, s>>>(field, x, pitch, nlat, out);
     return hipGetLastError();
 }
 hipError_t launch_finish_mean(double *dst, double *sum, double nt, size_t n, hipStream_t s) {

@@ -370,6 +370,21 @@ int ebm_get_field(ebm_handle_t h, int field, double *host) {
     return EBM_OK;
 }
 
+int ebm_hemispheric_mean(ebm_handle_t h, int field, double *out) {
+    if (!h || !out) return fail(EBM_ERR_ARG, "ebm_hemispheric_mean: null argument");
+    if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_hemispheric_mean: field not part of this model");
+    HIPCHK(hipSetDevice(h->device));
+    double *dev = nullptr;
+    HIPCHK(hipMalloc(&dev, sizeof(double) * (size_t)h->ncol));
+    hipError_t e = ebm::launch_hemispheric_mean(h->field[field], h->geom + (size_t)ebm::G_X * h->gstride, (int)h->pitch,
+                                                h->nlat, h->ncol, dev, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dev, sizeof(double) * (size_t)h->ncol, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("ebm_hemispheric_mean: ") + hipGetErrorString(e));
+    return EBM_OK;
+}
+
 int ebm_field_device_ptr(ebm_handle_t h, int field, double **dptr, long long *pitch) {
     if (!h || !dptr) return fail(EBM_ERR_ARG, "ebm_field_device_ptr: null argument");
     if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_field_device_ptr: field not part of this model");

@@ -102,6 +102,12 @@ class Engine:
         names = names or (self.prognostic + self.diagnostic)
         return {k: self.get_field(k) for k in names}
 
+    def hemispheric_mean(self, name: str) -> np.ndarray:
+        """Per-column hemispheric mean of a field, reduced on the device (ebm_hemispheric_mean)."""
+        out = np.empty(self.ncol)
+        check(self.lib.ebm_hemispheric_mean(self._h, FIELD[name], dptr(out)), "ebm_hemispheric_mean")
+        return out
+
     def field_device_ptr(self, name: str):
         p, pitch = C.c_void_p(), C.c_longlong()
         check(self.lib.ebm_field_device_ptr(self._h, FIELD[name], C.byref(p), C.byref(pitch)),

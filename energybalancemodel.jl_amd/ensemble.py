@@ -26,9 +26,10 @@ def shard_columns(ncol: int, world_size: int, rank: int) -> slice:
 
 
 def hemispheric_mean(vec: np.ndarray, x: np.ndarray) -> np.ndarray:
-    """Trapezoid integral over x of each column (reference src/utilities.jl:397-403)."""
+    """Trapezoid integral over x of each column (reference src/utilities.jl:397-403), summed
+    strictly left to right as the reference's loop does (np.cumsum is sequential)."""
     v = np.asarray(vec, dtype=np.float64)
-    return np.sum((v[..., :-1] + v[..., 1:]) * (x[1:] - x[:-1]) / 2.0, axis=-1)
+    return np.cumsum((v[..., :-1] + v[..., 1:]) * (x[1:] - x[:-1]) / 2.0, axis=-1)[..., -1]
 
 
 class EnsembleRun:

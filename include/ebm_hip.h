@@ -88,6 +88,10 @@ const char *ebm_version(void);
 /* Copy a whole field host<->device ([ncol][nlat] doubles, synchronous). */
 int ebm_set_field(ebm_handle_t h, int field, const double *host);
 int ebm_get_field(ebm_handle_t h, int field, double *host);
+/* hemispheric_mean (src/utilities.jl:397-403) of a field, per column, reduced on the device in the
+ * reference's summation order (bit-identical): out[ncol] on the host.  Ensemble diagnostics are
+ * O(columns) instead of O(state).  Synchronous. */
+int ebm_hemispheric_mean(ebm_handle_t h, int field, double *out);
 /* Device pointer of a field and its row pitch in elements (>= nlat), for zero-copy users
  * (e.g. a torch tensor view).  The pointer stays valid until ebm_destroy. */
 int ebm_field_device_ptr(ebm_handle_t h, int field, double **dptr, long long *pitch);

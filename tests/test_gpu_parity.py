@@ -602,6 +602,29 @@ def test_forcing_set_after_graph_capture_is_honoured(pkg, monkeypatch):
     assert np.any(out["1"]["Ew"][0] != out["1"]["Ew"][1])
 
 
+def test_hemispheric_mean_on_device_is_bit_exact(pkg):
+    """ebm_hemispheric_mean reduces in the reference's order (src/utilities.jl:397-403): equal,
+    bit for bit, to the sequential host loop on the downloaded field — values, NaNs and all."""
+    for nlat, ncol in ((180, 3), (1000, 5), (4096, 2)):
+        st = pkg.SpaceTime("sin", nlat, 2000 if nlat == 180 else 1048576, 1)
+        par = pkg.default_parameters("MIZ")
+        with make_engine(pkg, "MIZ", st, par, ncol) as eng:
+            eng.set_column_forcing(np.linspace(-2.0, 2.0, ncol))
+            eng.set_time_table(st.t)
+            eng.run(0, 40, None, True)
+            for name in ("T", "phi", "Ti"):                # Ti carries NaN sentinels
+                field = eng.get_field(name)
+                got = eng.hemispheric_mean(name)
+                ref = np.empty(ncol)
+                for c in range(ncol):
+                    acc = 0.0
+                    for i in range(nlat - 1):
+                        acc += (field[c, i] + field[c, i + 1]) * (st.x[i + 1] - st.x[i]) / 2.0
+                    ref[c] = acc
+                assert np.array_equal(got, ref, equal_nan=True), (nlat, name)
+                assert np.array_equal(got, pkg.hemispheric_mean(field, st.x), equal_nan=True)
+
+
 def test_integrate_classic_surface(pkg, oracle):
     g = load_golden("classic_identity_180_2000.npz")
     st = pkg.SpaceTime("identity", 180, 2000, 1)
