@@ -69,8 +69,15 @@ def cpu_baseline(pkg, wl, st, par, state, fcol, first_step, budget_s):
     t0 = time.perf_counter()
     co.miz_run(kid, st.x, dict(par), st.dt, ct, np.zeros(nsteps), fc, sub, nthreads=cores)
     dt = time.perf_counter() - t0
+    # the same port on ONE core, a short sample (single-thread figure beside the OpenMP one)
+    one = {k: np.ascontiguousarray(v[:8]) for k, v in sub.items()}
+    n1 = max(2, int(2.0 * rate / cores / (8 * nlat)))
+    t0 = time.perf_counter()
+    co.miz_run(kid, st.x, dict(par), st.dt, table(n1), np.zeros(n1), None if fc is None else fc[:8], one, nthreads=1)
+    rate1 = 8 * nlat * n1 / (time.perf_counter() - t0)
     return {
         "value": ncols * nlat * nsteps / dt, "unit": "grid-cell-steps/s", "cores": cores,
+        "value_single_core": rate1,
         "kind": "port",
         "sample": f"{nsteps} steps x {ncols} columns x {nlat} latitudes of the spun-up state "
                   f"(oracle/ebm_oracle.c, gcc -O2 -fopenmp, {dt:.1f} s)",
