@@ -304,6 +304,52 @@ def test_unsupported_and_bad_arguments(pkg):
 
 
 # ---- edge cases of the state ------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(24))
+def test_randomized_states_one_step(pkg, coracle, seed):
+    """Seeded fuzz: random grid length and kind, random (physically loose) states mixing open
+    water, thin and thick ice, phi = 0 / 1 / in between, floes at Dmin / Dmax / 0, inconsistent
+    Ei, random warm-start signs, random forcing and time of year, perturbed parameters.  One step
+    on the GPU against the oracle from identical inputs; sentinels must coincide."""
+    rng = np.random.default_rng(1000 + seed)
+    nlat = int(rng.choice([2, 3, 5, 17, 64, 65, 127, 180, 256, 300, 511, 777]))
+    ncol = int(rng.integers(1, 5))
+    kind = "sin" if rng.random() < 0.6 else "identity"
+    nt = int(max(2000, 0.7 * nlat * nlat))                    # near the explicit stability limit
+    st = pkg.SpaceTime(kind, nlat, nt, 1)
+    par = pkg.default_parameters("MIZ")
+    for k in ("D", "A", "B", "S1", "a0", "ai", "Fb", "k", "m1", "rl", "kappa"):
+        par[k] = par[k] * float(rng.uniform(0.8, 1.25))
+    shape = (ncol, nlat)
+    ice = rng.random(shape) < 0.6
+    h = np.where(ice, rng.choice([par["hmin"], 0.3, 1.0, 3.0], size=shape) * rng.uniform(0.5, 1.5, shape), 0.0)
+    phi = np.where(ice, rng.choice([0.0, 0.05, 0.5, 0.995, 1.0], size=shape), 0.0)
+    D = np.where(ice, rng.choice([0.0, par["Dmin"], 10.0, par["Dmax"]], size=shape), 0.0)
+    Ei = -par["Lf"] * h * phi * np.where(rng.random(shape) < 0.8, 1.0, rng.uniform(0.0, 2.0, shape))
+    Ew = par["cw"] * rng.uniform(-0.5, 12.0, shape) * (1.0 - 0.9 * phi)
+    T0 = rng.uniform(-20.0, 5.0, shape)
+    state = dict(Ei=Ei, Ew=Ew, h=h, D=D, phi=phi, T0=T0)
+    state = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in state.items()}
+    fcol = rng.uniform(-5.0, 5.0, ncol)
+    ti = int(rng.integers(0, nt))
+    ct = ctab(pkg, st)[ti:ti + 1]
+    f_step = np.array([float(rng.uniform(-2.0, 2.0))])
+    with make_engine(pkg, "MIZ", st, par, ncol) as eng:
+        eng.set_state(state)
+        eng.set_column_forcing(fcol)
+        eng.set_time_table(st.t)
+        eng.run(ti, 1, f_step, True)
+        got = eng.get_state(ALL)
+        cnt = eng.counters()
+    kid = 0 if kind == "identity" else 1
+    diag, ocnt = coracle.miz_run(kid, st.x, dict(par), st.dt, ct, f_step, fcol, state)
+    ref = dict(state)
+    ref.update(diag)
+    for k in ALL:
+        assert np.array_equal(np.isnan(got[k]), np.isnan(ref[k])), f"{k}: NaN pattern (seed {seed})"
+    check_all(got, ref, size_tol(TOL_STEP, nlat) * 10, what=f"seed {seed} {kind} {nlat}x{ncol}")
+    assert cnt["solves"] == ocnt[0], (cnt, ocnt)
+
+
 def test_nan_inf_and_saturated_states(pkg, coracle):
     """phi == 1 (division by zero in water_temp: 0/0 -> NaN -> 0, x/0 -> Inf kept), h == 0 with
     phi != 0, D == 0 with ice, NaN in a prognostic: the sentinels and non-finite values must
@@ -402,6 +448,37 @@ def test_classic_sizes_vs_oracle(pkg, coracle, nlat, ncol):
     ref = dict(state)
     ref.update(out)
     check_all(got, ref, size_tol(TOL_SHORT, nlat), names=("E", "Tg", "T", "h"), what=f"classic {nlat}x{ncol}")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_classic_randomized_states_one_step(pkg, coracle, seed):
+    """Seeded fuzz of the classic step: random length, random enthalpies around zero (so that the
+    Bool masks E > 0, E < 0, E >= 0, T0 < 0 all flip within a column, including E == 0 exactly),
+    random ghost layer, forcing and time index."""
+    rng = np.random.default_rng(77 + seed)
+    nlat = int(rng.choice([2, 9, 64, 129, 180, 500, 1024]))
+    ncol = int(rng.integers(1, 4))
+    st = pkg.SpaceTime("identity", nlat, 2000, 1)
+    par = pkg.default_parameters("Classic")
+    E = par["cw"] * rng.uniform(-8.0, 25.0, (ncol, nlat))
+    E[rng.random((ncol, nlat)) < 0.05] = 0.0
+    Tg = rng.uniform(-25.0, 30.0, (ncol, nlat))
+    state = dict(E=np.ascontiguousarray(E), Tg=np.ascontiguousarray(Tg))
+    fcol = rng.uniform(-3.0, 3.0, ncol)
+    ti = int(rng.integers(0, st.nt))
+    ct = ctab(pkg, st)
+    with make_engine(pkg, "Classic", st, par, ncol) as eng:
+        eng.set_state(state)
+        eng.set_column_forcing(fcol)
+        eng.set_time_table(st.t)
+        eng.run(ti, 1, None, True)
+        got = eng.get_state(("E", "Tg", "T", "h"))
+    out = coracle.classic_run(st.x, dict(par), st.dt, ct[[ti]], ct[[(ti + 1) % st.nt]], np.zeros(1), fcol, state)
+    ref = dict(state)
+    ref.update(out)
+    for k in ("E", "T", "h"):                                  # pointwise physics: bit-exact
+        assert np.array_equal(got[k], ref[k], equal_nan=True), f"{k} (seed {seed})"
+    assert scaled_err(got["Tg"], ref["Tg"]) <= size_tol(TOL_STEP, nlat), f"Tg (seed {seed})"
 
 
 def test_device_division_is_ieee(pkg):
