@@ -38,6 +38,7 @@ WORKLOADS = {
     "miz_4096x2048": ("MIZ", "sin", 4096, 2048, 1048576),
     "miz_1024x512x32": ("MIZ", "sin", 1024, 512 * 32, 65536),
     "miz_1440x1": ("MIZ", "sin", 1440, 1, 131072),
+    "miz_2048x4096": ("MIZ", "sin", 2048, 4096, 262144),     # same cells and bytes as the headline, half-length meridians
     "classic_1024x512": ("Classic", "identity", 1024, 512, 2000),
 }
 
