@@ -236,11 +236,12 @@ def test_graph_replay_equals_direct_launches(pkg, monkeypatch, model):
         assert np.array_equal(out["0"][k], out["1"][k], equal_nan=True), k
 
 
-def test_l2_prefetch_does_not_change_results(pkg, monkeypatch):
-    """Long meridians (one workgroup per CU): every workgroup prefetches into L2 the inputs of the
-    workgroup `EBM_PREFETCH_COLS` columns ahead (default: the CU count) with LDS-DMA loads whose
-    data is discarded.  Off, default and an odd distance: bitwise identical state."""
-    nlat, ncol, nt, nsteps = 4096, 520, 1048576, 12
+@pytest.mark.parametrize("nlat,ncol,nt", [(4096, 520, 1048576), (2048, 600, 262144)])
+def test_l2_prefetch_does_not_change_results(pkg, monkeypatch, nlat, ncol, nt):
+    """Long meridians (one or two workgroups per CU): every workgroup prefetches into L2 the inputs
+    of the workgroup `EBM_PREFETCH_COLS` columns ahead (default: CU count x workgroups per CU) with
+    LDS-DMA loads whose data is discarded.  Off, default and an odd distance: bitwise identical state."""
+    nsteps = 12
     st = pkg.SpaceTime("sin", nlat, nt, 1)
     par = pkg.default_parameters("MIZ")
     fcol = 2.0 * np.sin(np.arange(ncol) / 9.0)
