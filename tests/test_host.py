@@ -159,3 +159,30 @@ def test_broadcast_inputs_single_process(pkg):
     got = pkg.broadcast_inputs(dict(x=x[::2], f=[1, 2, 3]))
     assert np.array_equal(got["x"], x[::2]) and got["x"].flags["C_CONTIGUOUS"]
     assert got["f"].dtype == np.float64
+
+
+def test_schedule_words_follow_the_forcing_domain(pkg):
+    """The 9 words handed to ebm_set_column_schedule are the Forcing's own fields
+    (src/infrastructure.jl:208-241): evaluating them as the kernel does reproduces the call
+    operator (:294-307) at every point, including the breakpoints themselves."""
+    words = pkg.engine.schedule_words
+
+    def device_eval(w, T):
+        base, peak, cool, up, down, d1, d2, d3, d4 = w
+        if T < d1:
+            return base
+        if T < d2:
+            return base + up * (T - d1)
+        if T < d3:
+            return peak
+        if T < d4:
+            return peak + down * (T - d3)
+        return cool
+
+    for f in (pkg.Forcing(0.0, 5.0, -5.0, (10, 10), (0.5, -0.5)), pkg.Forcing(1.0, 3.0, 0.0, (0, 0), (2.0, -1.5)),
+              pkg.Forcing(0.75)):
+        w = words(f)
+        assert len(w) == 9
+        for T in list(np.linspace(0.0, 60.0, 481)) + [float(d) for d in f.domain]:
+            assert device_eval(w, T) == f(T), (repr(f), T)
+    assert words(pkg.Forcing(0.0, 5.0, -5.0, (10, 10), (0.5, -0.5)))[5:] == [10.0, 20.0, 30.0, 50.0]
