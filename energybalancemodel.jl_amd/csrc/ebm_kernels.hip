@@ -826,6 +826,9 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) classic_step_kernel(co
     load_chunk<C>(ge + G_AW * a.gstride, k0, aw);
     load_chunk<C>(ge + G_SB * a.gstride, k0, Sb);
     load_chunk<C>(ge + G_KDIAG * a.gstride, k0, kd);
+    double ca[C], cc[C], xs[C];                            // off-diagonals of kappa: fetched with the rest
+    load_chunk<C>(ge + G_KSUB * a.gstride, k0, ca);
+    load_chunk<C>(ge + G_KSUP * a.gstride, k0, cc);
     double b[C], d[C], oT[C], oh[C];
 #pragma unroll
     for (int i = 0; i < C; ++i) {
@@ -853,9 +856,6 @@ __global__ void __launch_bounds__(MizCfg<C>::kMaxThreads) classic_step_kernel(co
         store_chunk<C>(st + C_T * a.fstride, oT, k0, nlat);
         store_chunk<C>(st + C_h * a.fstride, oh, k0, nlat);
     }
-    double ca[C], cc[C], xs[C];
-    load_chunk<C>(ge + G_KSUB * a.gstride, k0, ca);
-    load_chunk<C>(ge + G_KSUP * a.gstride, k0, cc);
     partition_solve<C>(ca, b, cc, d, xs, t, T, P0, P1);   // Implicit Euler for Tg, :55-63
     store_chunk<C>(st + C_Tg * a.fstride, xs, k0, nlat);
 }
