@@ -199,3 +199,61 @@ def test_oracle_integrate_savesol_semantics(oracle):
     assert len(last.raw["E"]) == 400
     assert np.array_equal(last.raw["T"][399], sols.raw["T"][799], equal_nan=True)
     assert last.ts[0] == pytest.approx(1.0 + st.dt / 2)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_c_port_equals_numpy_on_random_states(oracle, coracle, seed):
+    """The two restatements (NumPy, C) must agree bit for bit not only along the golden
+    trajectories but from arbitrary states: seeded random grids, perturbed parameters, states mixing
+    open water / ice / saturated cells, random warm starts and forcing — one step each."""
+    rng = np.random.default_rng(500 + seed)
+    nx = int(rng.choice([2, 3, 7, 33, 64, 100, 181]))
+    kind, kid = ("sin", 1) if rng.random() < 0.6 else ("identity", 0)
+    st = oracle.SpaceTime(kind, nx, int(max(2000, 0.7 * nx * nx)), 1)
+    par = dict(oracle.default_parameters("MIZ"))
+    for k in ("D", "A", "B", "S1", "a0", "ai", "Fb", "k", "m1", "rl", "kappa"):
+        par[k] = par[k] * float(rng.uniform(0.8, 1.25))
+    ice = rng.random(nx) < 0.6
+    h = np.where(ice, rng.choice([par["hmin"], 0.3, 1.0, 3.0], size=nx) * rng.uniform(0.5, 1.5, nx), 0.0)
+    phi = np.where(ice, rng.choice([0.0, 0.05, 0.5, 0.995, 1.0], size=nx), 0.0)
+    D = np.where(ice, rng.choice([0.0, par["Dmin"], 10.0, par["Dmax"]], size=nx), 0.0)
+    Ei = -par["Lf"] * h * phi * np.where(rng.random(nx) < 0.8, 1.0, rng.uniform(0.0, 2.0, nx))
+    Ew = par["cw"] * rng.uniform(-0.5, 12.0, nx) * (1.0 - 0.9 * phi)
+    T0 = rng.uniform(-20.0, 5.0, nx)
+    f = float(rng.uniform(-3.0, 3.0))
+    ct = oracle.cos2pit(float(st.t[int(rng.integers(0, st.nt))]))
+    geom = oracle.DiffusionGeometry(kind, st.x, par["D"])
+    new, T0n, nit, ok = oracle.step_miz(ct, f, dict(Ei=Ei, Ew=Ew, h=h, D=D, phi=phi), T0.copy(), st.x, st.dt, geom, par)
+    state = {k: np.ascontiguousarray(v[None], dtype=np.float64) for k, v in dict(Ei=Ei, Ew=Ew, h=h, D=D, phi=phi, T0=T0).items()}
+    diag, cnt = coracle.miz_run(kid, st.x, par, st.dt, np.array([ct]), np.array([f]), None, state)
+    assert ok and cnt[0] == nit and cnt[1] == 0
+    for k in PROG:
+        assert np.array_equal(state[k][0], new[k], equal_nan=True), k
+    assert np.array_equal(state["T0"][0], T0n, equal_nan=True)
+    for k in DIAG:
+        assert np.array_equal(diag[k][0], new[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_classic_c_port_equals_numpy_on_random_states(oracle, coracle, seed):
+    """Classic step from random states (enthalpies around zero, exact zeros included, so every
+    Bool mask flips inside a column): NumPy and C restatements agree bit for bit."""
+    rng = np.random.default_rng(900 + seed)
+    nx = int(rng.choice([2, 5, 64, 129, 180]))
+    st = oracle.SpaceTime("identity", nx, 2000, 1)
+    par = dict(oracle.default_parameters("Classic"))
+    for k in ("D", "A", "B", "S1", "a0", "ai", "Fb", "k", "cg"):
+        par[k] = par[k] * float(rng.uniform(0.85, 1.2))
+    E = par["cw"] * rng.uniform(-8.0, 25.0, nx)
+    E[rng.random(nx) < 0.08] = 0.0
+    Tg = rng.uniform(-25.0, 30.0, nx)
+    f = float(rng.uniform(-3.0, 3.0))
+    ti = int(rng.integers(0, st.nt))
+    ct_i, ct_n = oracle.cos2pit(float(st.t[ti])), oracle.cos2pit(float(st.t[(ti + 1) % st.nt]))
+    stat = oracle.ClassicStatics(st.x, nx, st.dt, par)
+    with np.errstate(all="ignore"):
+        new = oracle.step_classic(ct_i, ct_n, f, dict(E=E.copy(), Tg=Tg.copy()), st.x, st.dt, stat, par)
+    state = dict(E=np.ascontiguousarray(E[None]), Tg=np.ascontiguousarray(Tg[None]))
+    out = coracle.classic_run(st.x, par, st.dt, np.array([ct_i]), np.array([ct_n]), np.array([f]), None, state)
+    for k, got in (("E", state["E"][0]), ("Tg", state["Tg"][0]), ("T", out["T"][0]), ("h", out["h"][0])):
+        assert np.array_equal(got, new[k], equal_nan=True), k
