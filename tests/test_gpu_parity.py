@@ -143,6 +143,37 @@ def test_miz_year_on_reference_config_shadows_the_oracle(pkg, coracle):
     assert abs(int(np.argmax(got["phi"] > 0)) - int(np.argmax(end["phi"] > 0))) <= 1
 
 
+def test_headline_meridians_shadow_the_oracle(pkg, coracle):
+    """The bench configuration (4096 latitudes, sin grid, nt = 2^20) is as sensitive at the ice edge
+    as the reference's test configuration: beyond ~100 steps cells flip between ice and water in
+    one run and not in the other.  Same shadowing criterion, on 8 meridians of the bench's forcing
+    ramp: through 1000 steps the GPU stays inside 5x the oracle's own 4-ulp envelope."""
+    nlat, nt, ncol = 4096, 1048576, 8
+    st = pkg.SpaceTime("sin", nlat, nt, 1)
+    par = pkg.default_parameters("MIZ")
+    pert = dict(par)
+    pert["Fb"] = par["Fb"] * (1.0 + 2.0 ** -50)
+    fcol = 0.5 * np.sin(2.0 * np.pi * np.arange(ncol) / ncol)
+    ct = ctab(pkg, st)
+    ref = {k: np.zeros((ncol, nlat)) for k in PROG + ("T0",)}
+    alt = {k: np.zeros((ncol, nlat)) for k in PROG + ("T0",)}
+    with make_engine(pkg, "MIZ", st, par, ncol) as eng:
+        eng.set_column_forcing(fcol)
+        eng.set_time_table(st.t)
+        done = 0
+        for s in (20, 50, 200, 500, 1000):
+            n = s - done
+            coracle.miz_run(1, st.x, dict(par), st.dt, ct[done:s], np.zeros(n), fcol, ref)
+            coracle.miz_run(1, st.x, pert, st.dt, ct[done:s], np.zeros(n), fcol, alt)
+            eng.run(done, n, None, False)
+            done = s
+            got = eng.get_state(PROG)
+            dist = max(scaled_err(got[k], ref[k]) for k in PROG)
+            envelope = max(scaled_err(alt[k], ref[k]) for k in PROG)
+            assert dist <= max(size_tol(TOL_SHORT, nlat), 5.0 * envelope), f"step {s}: {dist:.2e} vs {envelope:.2e}"
+        assert eng.counters()["cap_hits"] == 0
+
+
 def test_t0_meets_reference_solver_criterion(pkg, coracle):
     """The reference accepts T0 when |T0eq(T0)| <= abstol = 1e-8 (src/miz.jl:58-59): the
     GPU's T0 must satisfy the reference's residual function at that level."""
