@@ -39,6 +39,7 @@ WORKLOADS = {
     "miz_1024x512x32": ("MIZ", "sin", 1024, 512 * 32, 65536),
     "miz_1440x1": ("MIZ", "sin", 1440, 1, 131072),
     "miz_2048x4096": ("MIZ", "sin", 2048, 4096, 262144),     # same cells and bytes as the headline, half-length meridians
+    "miz_8192x1024": ("MIZ", "sin", 8192, 1024, 4194304),    # longest supported meridians (16 cells per thread, no LDS stash)
     "classic_1024x512": ("Classic", "identity", 1024, 512, 2000),
 }
 
