@@ -1,26 +1,39 @@
 #!/usr/bin/env python
 """bench.py — grid-cell-steps/s and achieved HBM GB/s of the MIZ step on MI355X.
 
-Workload (BASELINE.json configs[3]): 2-D 4096 x 2048 MIZ model on the sin
-grid — 2048 independent meridians of 4096 latitudes per GPU — nt = 1,048,576 steps/year
-(explicit stability), all-zero initial prognostics as in the reference test, per-column
-forcing f[lon] = 0.5*sin(2*pi*lon/nlon), `--spinup` untimed spin-up steps so ice and open
-water and the T0 solve are all live.  A "step" is one time step of the whole grid = one kernel
-launch (K = 1 step per launch).  With N GPUs every rank integrates its own 4096 x 2048 block
-(columns are independent: weak scaling, no collective in the time loop).
+Headline workload (BASELINE.json configs[3]): 2-D 4096 x 2048 MIZ model on the
+sin grid — 2048 independent meridians of 4096 latitudes per GPU — nt = 1,048,576 steps/year
+(explicit stability), all-zero initial prognostics as in the reference test, per-column forcing
+f[lon] = 0.5*sin(2*pi*lon/nlon), `--spinup` untimed spin-up steps so ice and open water and the T0
+solve are all live.  A "step" is one time step of the whole grid = one kernel launch (K = 1 step per
+launch).  With N GPUs every rank integrates its own 4096 x 2048 block (columns are independent: weak
+scaling, no collective in the time loop).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = 96 B per cell-step (read + write of
-Ei, Ew, h, D, phi and the T0 warm start) x cells per launch / average launch
-duration measured with HIP events on the stream the kernels run on.
+Order of events: spin-up -> pre-roll (>= 0.25 s of untimed steps, so that the GPU is at its working
+clocks whatever `--warmup` says) -> W warm-up steps -> `--repeats` blocks of EXACTLY K steps, each
+bracketed by barrier + synchronize on both sides and timed with the host clock (max over ranks) and
+with HIP events on the stream the kernels run on -> only then the state download, the ice fraction
+and the CPU baseline.  `ms_per_step` / `value` are the MEDIAN block; every block is printed.
+
+Other workloads (never the headline; `metric` names them):
+  --workload miz_180x1 / miz_1440x1 [--steps-per-launch K]   1-D shapes of configs[0] / [1]; with K > 1
+        the fused-K path (ebm_run_fused: K steps per launch, state in registers), reported separately
+  --workload miz_1024x512x32_integrate   ebm_integrate with the annual-mean sums of all 10 solution
+        variables taken from the step kernel's registers (savesol! fused; avg on, raw off)
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per cell-step (MIZ: 96 B =
+read + write of Ei, Ew, h, D, phi and the T0 warm start; integrate: + 16 B per saved
+variable for the read-modify-write of its running sum) x cells per launch / median launch duration.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -32,16 +45,19 @@ import __graft_entry__ as graft  # noqa: E402
 
 BYTES_PER_CELL_STEP = 96.0       # MIZ, state only
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PREROLL_S = 0.25
 
 WORKLOADS = {
     # name: (model, grid kind, nlat, ncol, nt)
     "miz_4096x2048": ("MIZ", "sin", 4096, 2048, 1048576),
     "miz_1024x512x32": ("MIZ", "sin", 1024, 512 * 32, 65536),
+    "miz_1024x512x32_integrate": ("MIZ", "sin", 1024, 512 * 32, 65536),
+    "miz_180x1": ("MIZ", "sin", 180, 1, 2000),               # the reference's own test / docstring shape
     "miz_1440x1": ("MIZ", "sin", 1440, 1, 131072),
     "miz_2048x4096": ("MIZ", "sin", 2048, 4096, 262144),     # same cells and bytes as the headline, half-length meridians
-    "miz_8192x1024": ("MIZ", "sin", 8192, 1024, 4194304),    # longest supported meridians (16 cells per thread, no LDS stash)
     "classic_1024x512": ("Classic", "identity", 1024, 512, 2000),
 }
+MIZ_VARS = ("E", "T", "h", "Ei", "Ew", "Ti", "Tw", "D", "phi", "n")
 
 
 def cpu_baseline(pkg, wl, st, par, state, fcol, first_step, budget_s):
@@ -72,11 +88,12 @@ def cpu_baseline(pkg, wl, st, par, state, fcol, first_step, budget_s):
     co.miz_run(kid, st.x, dict(par), st.dt, ct, np.zeros(nsteps), fc, sub, nthreads=cores)
     dt = time.perf_counter() - t0
     # the same port on ONE core, a short sample (single-thread figure beside the OpenMP one)
-    one = {k: np.ascontiguousarray(v[:8]) for k, v in sub.items()}
-    n1 = max(2, int(2.0 * rate / cores / (8 * nlat)))
+    nc1 = min(8, ncols)
+    one = {k: np.ascontiguousarray(v[:nc1]) for k, v in sub.items()}
+    n1 = max(2, int(2.0 * rate / cores / (nc1 * nlat)))
     t0 = time.perf_counter()
-    co.miz_run(kid, st.x, dict(par), st.dt, table(n1), np.zeros(n1), None if fc is None else fc[:8], one, nthreads=1)
-    rate1 = 8 * nlat * n1 / (time.perf_counter() - t0)
+    co.miz_run(kid, st.x, dict(par), st.dt, table(n1), np.zeros(n1), None if fc is None else fc[:nc1], one, nthreads=1)
+    rate1 = nc1 * nlat * n1 / (time.perf_counter() - t0)
     return {
         "value": ncols * nlat * nsteps / dt, "unit": "grid-cell-steps/s", "cores": cores,
         "value_single_core": rate1,
@@ -91,9 +108,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the median is reported")
     ap.add_argument("--spinup", type=int, default=2000)
     ap.add_argument("--workload", default="miz_4096x2048", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU baseline work (0 = skip)")
+    ap.add_argument("--steps-per-launch", type=int, default=1,
+                    help="K > 1: fused-K stepping (ebm_run_fused), reported as its own metric")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -118,13 +138,17 @@ def main():
     pkg = graft.load_package()
     wl = WORKLOADS[args.workload]
     model, kind, nlat, ncol, nt = wl
+    integrate = args.workload.endswith("_integrate")
+    K = max(1, args.steps_per_launch)
     st = pkg.SpaceTime(kind, nlat, nt, 1)
     par = pkg.default_parameters(model)
     lon = np.arange(ncol) + rank * ncol                      # this rank's block of columns
-    if args.workload == "miz_1024x512x32":
+    if args.workload.startswith("miz_1024x512x32"):
         # BASELINE configs[4] / SURVEY 8(d) cfg5: 32 members of 512 meridians per GPU, member m of 256
         # forced by the constant f_m = -2 + 4 m/255 W/m2
         fcol = -2.0 + 4.0 * ((lon // 512) % 256) / 255.0
+    elif ncol == 1:
+        fcol = np.zeros(1)                                   # the reference's Forcing(0.0)
     else:
         fcol = 0.5 * np.sin(2.0 * np.pi * lon / ncol)
     eng = pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval),
@@ -136,68 +160,113 @@ def main():
         eng.set_field("Tg", np.tile(Ts, (ncol, 1)))
     eng.set_column_forcing(fcol)
     eng.set_time_table(st.t)
-    step = 0
-    eng.run(step, args.spinup, None, False); step += args.spinup
+    clock = {"step": 0}
+
+    def advance(n):
+        """n steps on the stream (asynchronous), the way this workload takes them."""
+        if integrate:
+            # a `year` of n steps of the same dt: annual-mean sums of all ten variables on every step,
+            # the means taken (and copied out) at its end; no raw output, no seasonal snapshots
+            i0 = clock["step"] % nt
+            eng.set_time_table(np.take(st.t, np.arange(i0, i0 + n) % nt))
+            eng.integrate(n, 1, None, True, 0, 0, MIZ_VARS, want_raw=False, want_seasonal=False, want_avg=True)
+        else:
+            eng.run(clock["step"], n, None, False, steps_per_launch=K)
+        clock["step"] += n
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()                                           # the handle's own (non-blocking) stream
+
+    eng.run(0, args.spinup, None, False)
+    clock["step"] = args.spinup
     eng.sync()
-    # state after spin-up (for the CPU baseline sample and the ice fraction)
+    # pre-roll: a fixed amount of untimed work right before the timed region
+    t0 = time.perf_counter()
+    probe = max(1, min(args.steps, 64))
+    advance(probe)
+    eng.sync()
+    per_step = (time.perf_counter() - t0) / probe
+    preroll = 0 if integrate else int(min(200000, max(0, PREROLL_S / max(per_step, 1e-7))))
+    if preroll:
+        advance(preroll)
+    advance(args.warmup) if args.warmup else None
+    eng.sync()
+    eng.reset_counters()
+
+    blocks_wall, blocks_ev = [], []
+    for _ in range(max(1, args.repeats)):
+        barrier()
+        t0 = time.perf_counter()
+        eng.timer_start()
+        advance(args.steps)
+        ev_ms = eng.timer_stop()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        blocks_wall.append(elapsed)
+        blocks_ev.append(ev_ms)
+    cnt = eng.counters()
+    info = eng.launch_info()
+    elapsed = statistics.median(blocks_wall)
+    ev_ms = statistics.median(blocks_ev)
+
+    # ---- after the timed region: diagnostics of the state that was timed, CPU baseline --------------
     cpu = None
     ice_fraction = None
     if model == "MIZ":
         state = {k: eng.get_field(k) for k in ("Ei", "Ew", "h", "D", "phi", "T0")}
         ice_fraction = float(np.mean(state["phi"] > 0))
         if rank == 0 and world == 1 and args.cpu_budget > 0:
-            cpu = cpu_baseline(pkg, wl, st, par, state, fcol, step, args.cpu_budget)
+            cpu = cpu_baseline(pkg, wl, st, par, state, fcol, clock["step"], args.cpu_budget)
         del state
-    eng.run(step, args.warmup, None, False); step += args.warmup
-    eng.sync()
-    eng.reset_counters()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    eng.timer_start()
-    eng.run(step, args.steps, None, False)
-    ev_ms = eng.timer_stop()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    cnt = eng.counters()
-    info = eng.launch_info()
     eng.close()
 
     cells = nlat * ncol
-    bpc = BYTES_PER_CELL_STEP if model == "MIZ" else 32.0
-    launch_s = ev_ms * 1e-3 / args.steps
-    achieved = bpc * cells / launch_s / 1e9
+    nsaved = len(MIZ_VARS) if integrate else 0
+    bpc = (BYTES_PER_CELL_STEP if model == "MIZ" else 32.0) + 16.0 * nsaved
+    launches = cnt["launches"] / max(1, args.repeats)        # kernel launches per timed block
+    launch_s = ev_ms * 1e-3 / max(1.0, launches)
+    achieved = bpc * cells * args.steps / (ev_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc):
+    pmc_key = args.workload if K == 1 else None
+    traffic_source = None
+    if pmc_key and os.path.exists(pmc):
         with open(pmc) as fh:
-            traffic = json.load(fh).get(args.workload)
+            doc = json.load(fh)
+        traffic = doc.get(pmc_key)
+        if traffic:
+            traffic_source = ("profiles/pmc_latest.json: " + str(doc.get("_detail", {}).get("source", "rocprofv3 --pmc of an earlier run"))
+                              + " — a tracked constant, NOT measured in this run")
+    name = args.workload + (f", {K} steps per launch (fused)" if K > 1 else "")
     out = {
-        "metric": "grid-cell-steps/sec (2D 4096x2048 MIZ model)" if args.workload == "miz_4096x2048"
-                  else f"grid-cell-steps/sec ({args.workload})",
+        "metric": "grid-cell-steps/sec (2D 4096x2048 MIZ model)" if (args.workload == "miz_4096x2048" and K == 1)
+                  else f"grid-cell-steps/sec ({name})",
         "value": cells * world * args.steps / elapsed,
         "unit": "grid-cell-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
+        "repeats": len(blocks_wall),
+        "blocks_ms_per_step": [b * 1e3 / args.steps for b in blocks_wall],
+        "preroll_steps": preroll,
         "config": {
-            "workload": f"{args.workload}: {model} model, {nlat} lat x {ncol} meridians per GPU, "
+            "workload": f"{name}: {model} model, {nlat} lat x {ncol} meridians per GPU, "
                         f"{kind} grid, nt={nt}, {args.spinup} spin-up steps from zero state, "
-                        + ("f[member]=-2+4*member/255" if args.workload == "miz_1024x512x32"
-                           else "f[lon]=0.5*sin(2*pi*lon/nlon)"),
-            "steps_per_launch": 1,
+                        + ("f[member]=-2+4*member/255" if args.workload.startswith("miz_1024x512x32")
+                           else ("f=0" if ncol == 1 else "f[lon]=0.5*sin(2*pi*lon/nlon)"))
+                        + (", ebm_integrate: annual-mean sums of 10 variables from the step kernel's registers, "
+                           "means copied out at the end of every block" if integrate else ""),
+            "steps_per_launch": (cnt["steps"] / cnt["launches"]) if cnt["launches"] else None,
             "ice_covered_fraction": ice_fraction,
-            "mean_tridiagonal_solves_per_column_step": (cnt["solves"] / (args.steps * ncol)) if model == "MIZ" else 1.0,
+            "mean_tridiagonal_solves_per_column_step": (cnt["solves"] / (cnt["steps"] * ncol)) if model == "MIZ" and cnt["steps"] else 1.0,
             "t0_cap_hits": cnt["cap_hits"],
             "threads_per_workgroup": info["threads"], "cells_per_thread": info["cells_per_thread"],
             "lds_bytes_per_workgroup": info["lds_bytes"],
@@ -205,10 +274,12 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "kernel": "miz_step_kernel" if model == "MIZ" else "classic_step_kernel",
-            "algorithmic_bytes_per_launch": bpc * cells,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": ("miz_fused_kernel" if K > 1 and info["threads"] <= 512 else "miz_step_kernel") if model == "MIZ" else "classic_step_kernel",
+            "algorithmic_bytes_per_cell_step": bpc,
+            "algorithmic_bytes_per_launch": bpc * cells * cnt["steps"] / max(1, cnt["launches"]),
             "avg_launch_ms": launch_s * 1e3,
+            "blocks_event_ms_per_step": [b / args.steps for b in blocks_ev],
             # transparency: the kernel carries the T0 warm start as a bit mask, so it moves fewer bytes
             # than the contract's 96 B per cell-step; this is the rate of the counter-measured traffic
             "achieved_traffic_gbs": (traffic / launch_s / 1e9) if traffic else None,

@@ -24,9 +24,10 @@ PARAM_ORDER = ("D", "A", "B", "cw", "S0", "S1", "S2", "a0", "a2", "ai", "Fb", "k
                "cg", "tau", "Tm", "m1", "m2", "alpha", "rl", "Dmin", "Dmax", "hmin", "kappa")
 EXPORTS = (
     "ebm_create", "ebm_destroy", "ebm_last_error", "ebm_version", "ebm_set_field",
-    "ebm_get_field", "ebm_hemispheric_mean", "ebm_field_device_ptr", "ebm_set_column_forcing", "ebm_set_column_schedule",
+    "ebm_get_field", "ebm_hemispheric_mean", "ebm_hemispheric_mean_device", "ebm_get_field_device",
+    "ebm_field_device_ptr", "ebm_set_column_forcing", "ebm_set_column_schedule",
     "ebm_set_step_clock", "ebm_set_time_table",
-    "ebm_step", "ebm_run", "ebm_integrate", "ebm_sync", "ebm_get_counters",
+    "ebm_step", "ebm_run", "ebm_run_fused", "ebm_integrate", "ebm_sync", "ebm_get_counters",
     "ebm_reset_counters", "ebm_timer_start", "ebm_timer_stop", "ebm_launch_info",
     "ebm_selftest_divide",
 )
@@ -58,6 +59,8 @@ def load():
     lib.ebm_set_field.argtypes = [C.c_void_p, C.c_int, _dp]
     lib.ebm_get_field.argtypes = [C.c_void_p, C.c_int, _dp]
     lib.ebm_hemispheric_mean.argtypes = [C.c_void_p, C.c_int, _dp]
+    lib.ebm_hemispheric_mean_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.ebm_get_field_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.ebm_field_device_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_longlong)]
     lib.ebm_set_column_forcing.argtypes = [C.c_void_p, _dp]
@@ -66,6 +69,7 @@ def load():
     lib.ebm_set_time_table.argtypes = [C.c_void_p, C.c_int, _dp]
     lib.ebm_step.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int]
     lib.ebm_run.argtypes = [C.c_void_p, C.c_longlong, C.c_int, _dp, C.c_int]
+    lib.ebm_run_fused.argtypes = [C.c_void_p, C.c_longlong, C.c_int, _dp, C.c_int, C.c_int]
     lib.ebm_integrate.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.POINTER(C.c_int), _dp, _dp, _dp, _dp]
     lib.ebm_sync.argtypes = [C.c_void_p]

@@ -22,6 +22,10 @@ struct Params {
     double two_rl;      // 2.0*rl                                  src/miz.jl:91
     // classic (get_statics, src/classic.jl:18-29)
     double cg_tau, dt_tau, dc, M, kLf;
+    // Refined reciprocals of two constant divisors, produced ON THE DEVICE by the same routine the
+    // physics' IEEE division uses (derive_params_kernel), so that dividing through them gives the
+    // bits an in-kernel division gives: 1/dt (src/miz.jl:173) and 1/c_dn (src/miz.jl:127).
+    double rcp_dt, rcp_cdn;
 };
 
 // Device state: one slab, field slot s at state + s*fstride, each [ncol][pitch] with
@@ -29,7 +33,23 @@ struct Params {
 enum MizSlot { S_Ei = 0, S_Ew, S_h, S_D, S_phi, S_T0, S_Tw, S_Ti, S_n, S_E, S_T, S_MIZ_COUNT };
 enum ClassicSlot { C_E = 0, C_Tg, C_T, C_h, C_COUNT };
 
-// Per-latitude constant tables: one slab, table i at geom + i*gstride (gstride = pitch + 4).
+// The quantities a step produces per cell, in the order the kernels hold them in registers
+// (savesol! fusion: StepArgs::var_of maps each one to a saved-variable index or -1).
+enum MizQuantity { Q_Ei = 0, Q_Ew, Q_h, Q_D, Q_phi, Q_n, Q_E, Q_T, Q_Ti, Q_Tw, Q_MIZ_COUNT };
+enum ClassicQuantity { QC_E = 0, QC_Tg, QC_T, QC_h, QC_COUNT };
+constexpr int kMaxQuantities = 12;
+
+// What a step launch writes besides the prognostic state.
+enum OutMode {
+    OUT_STATE = 0,   // prognostics (+ warm-start mask) only
+    OUT_DIAG = 1,    // + T0 and the diagnostic fields
+    OUT_SAVE = 2,    // savesol! fused into the step: annual-mean running sums and/or a raw snapshot
+                     // from registers; the diagnostic fields only if write_diag
+    OUT_LOOP = 3,    // nfused steps in one launch (state through L2 between steps, long meridians);
+                     // the diagnostic fields after the last step if write_diag
+};
+
+// Per-latitude constant tables: one slab, table i at geom + i*gstride (gstride = pitch).
 //   G_X              st.x
 //   G_0..G_4         physics stencil, bit-exact restatement of the reference:
 //                      identity grid: sub, diag, sup of par.D*get_diffop  (infrastructure.jl:480-497)
@@ -61,6 +81,14 @@ struct StepArgs {
     int slot;
     int write_diag;
     int prefetch;                    // MIZ: L2 prefetch distance in columns (0 = off)
+    int nfused;                      // fused launches: steps in this launch, scalars from sched[slot .. slot+nfused)
+    // savesol! fused into the step (OUT_SAVE), src/infrastructure.jl:549-591:
+    double *sums;                    // annual-mean running sums [nvars][ncol*pitch] in the pair-split layout, or nullptr
+    long long sum_stride;            // ncol*pitch
+    double *stage;                   // raw snapshots [nvars][chunk][ncol][pitch], or nullptr
+    long long stage_var_stride;      // chunk*ncol*pitch
+    long long stage_offset;          // snapshot index * ncol*pitch
+    signed char var_of[kMaxQuantities];   // quantity -> saved-variable index, -1 = not saved
     unsigned long long *stamps;      // diagnostic builds only (EBM_STAMPS), else nullptr
 };
 
@@ -74,31 +102,25 @@ constexpr int kCounterShards = 64;
 constexpr int kSchedWords = 9;     // base, peak, cool, rate up, rate down, domain[1..4]
 constexpr int kMaxNewton = 50;
 
-LaunchCfg choose_launch(int nlat, bool prefer_c8);
+constexpr int kCells = 4;          // cells per thread (C): 32 contiguous bytes per lane and field
+constexpr int kMaxLat = 4096;      // one workgroup of <= 1024 threads owns a whole meridian
+constexpr int kFusedRegThreads = 512;   // up to here the fused-K kernel keeps the whole state in registers
+
+LaunchCfg choose_launch(int nlat);
 hipError_t prepare_kernels(const LaunchCfg &cfg);   // raises the dynamic-LDS limit if needed
-hipError_t launch_miz_step(const StepArgs &a, int grid_kind, const LaunchCfg &cfg, hipStream_t s);   // one workgroup per column
-hipError_t launch_classic_step(const StepArgs &a, int ncol, const LaunchCfg &cfg, hipStream_t s);
-// savesol! (src/infrastructure.jl:549-591) for one step, all saved variables in one launch:
-// running sums for the annual mean (padded [nvars][ncol*pitch] layout) and/or a packed snapshot
-// into the raw staging buffer ([nvars][chunk][ncol][nlat], snapshot index `stage_index`).
-struct SaveArgs {
-    const double *state;
-    long long fstride;
-    int slots[12];
-    int nvars, pitch, nlat, ncol;
-    double *sums;            // or nullptr
-    long long sum_stride;    // ncol*pitch
-    double *stage;           // or nullptr
-    long long stage_var_stride, stage_index;
-};
-hipError_t launch_savesol(const SaveArgs &a, hipStream_t s);
+// One workgroup per column.  mode: OutMode; OUT_LOOP runs a.nfused steps per launch.
+hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, hipStream_t s);
+hipError_t launch_classic_step(const StepArgs &a, int mode, const LaunchCfg &cfg, hipStream_t s);
+// rcp_dt / rcp_cdn of the device-resident parameter block (see Params)
+hipError_t launch_derive_params(Params *p_dev, hipStream_t s);
 // active set from the T0 field (after ebm_set_field(T0))
 hipError_t launch_mask_from_t0(const StepArgs &a, int ncol, const LaunchCfg &cfg, hipStream_t s);
 hipError_t launch_divide(const double *a, const double *b, double *q, int n, hipStream_t s);
 // out[col] = hemispheric_mean(field[col], x), src/utilities.jl:397-403 (sequential sum, bit-exact)
 hipError_t launch_hemispheric_mean(const double *field, const double *x, int pitch, int nlat, int ncol, double *out,
                                    hipStream_t s);
-// dst[i] = sum[i]/nt, sum[i] = 0
-hipError_t launch_finish_mean(double *dst, double *sum, double nt, size_t n, hipStream_t s);
+// annual_mean (src/infrastructure.jl:536-544): dst[col][k] = sum/nt with `sum` in the pair-split
+// layout of the step kernels, then sum = 0
+hipError_t launch_finish_mean(double *dst, double *sum, double nt, int ncol, int threads, hipStream_t s);
 
 }  // namespace ebm

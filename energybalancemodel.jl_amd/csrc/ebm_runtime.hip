@@ -49,6 +49,8 @@ struct ebm_ctx {
     unsigned long long *stamps = nullptr;          // diagnostic builds only
     int num_cus = 0;
     int prefetch = 0;                 // L2 prefetch distance of the MIZ kernel, columns (0 = off)
+    double *hm_dev = nullptr;         // ebm_hemispheric_mean: per-column results on the device
+    ebm::StepSched *fused_sched = nullptr;   // per-step scalars of the fused-K launches (kFusedTable entries)
     // hipGraph replay for launch-bound shapes (small grids): kGraphSteps step kernels per replay
     ebm::StepSched *sched_dev = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -182,14 +184,17 @@ ebm::StepArgs base_args(const ebm_ctx *h) {
     a.pitch = (int)h->pitch; a.nlat = h->nlat; a.ncol = h->ncol;
     a.stamps = h->stamps;
     a.prefetch = h->prefetch;
+    a.nfused = 1;
+    std::memset(a.var_of, -1, sizeof(a.var_of));
     return a;
 }
 
 constexpr int kGraphSteps = 64;
 
-hipError_t launch_step(ebm_ctx *h, const ebm::StepArgs &a) {
-    return (h->model == EBM_MODEL_MIZ) ? ebm::launch_miz_step(a, h->grid, h->cfg, h->stream)
-                                       : ebm::launch_classic_step(a, h->ncol, h->cfg, h->stream);
+// mode: ebm::OutMode.  The classic kernel decides about T, h at run time (write_diag).
+hipError_t launch_step(ebm_ctx *h, const ebm::StepArgs &a, int mode) {
+    return (h->model == EBM_MODEL_MIZ) ? ebm::launch_miz_step(a, h->grid, mode, h->cfg, h->stream)
+                                       : ebm::launch_classic_step(a, mode, h->cfg, h->stream);
 }
 
 // Capture kGraphSteps step kernels (node i reads sched_dev[i]) into a graph, once per handle.
@@ -203,7 +208,7 @@ int build_graph(ebm_ctx *h) {
         a.sched = h->sched_dev;
         a.slot = i;
         a.write_diag = 0;
-        e = launch_step(h, a);
+        e = launch_step(h, a, ebm::OUT_STATE);
     }
     hipError_t e2 = hipStreamEndCapture(h->stream, &graph);
     if (e != hipSuccess || e2 != hipSuccess) {
@@ -230,21 +235,63 @@ void invalidate_graph(ebm_ctx *h) {
     h->sched_dev = nullptr;
 }
 
-int do_step(ebm_ctx *h, double ct, double ct_next, double f, int write_diag, long long step) {
+// savesol! fused into a step launch (ebm::OUT_SAVE): where the running sums and the raw snapshot go
+struct SaveTarget {
+    double *sums = nullptr;
+    long long sum_stride = 0;
+    double *stage = nullptr;
+    long long stage_var_stride = 0, stage_offset = 0;
+    signed char var_of[ebm::kMaxQuantities];
+};
+
+int do_step(ebm_ctx *h, double ct, double ct_next, double f, int write_diag, long long step,
+            const SaveTarget *save = nullptr) {
     ebm::StepArgs a = base_args(h);
-    a.state = h->state; a.fstride = h->fstride; a.geom = h->geom; a.gstride = h->gstride;
-    a.fcol = h->fcol; a.p = h->p_dev; a.counters = h->counters;
-    a.pitch = (int)h->pitch; a.nlat = h->nlat; a.ncol = h->ncol;
     a.ct = ct; a.ct_next = ct_next; a.ft = f; a.write_diag = write_diag;
     a.tyear = year_time(h, step);
-    a.stamps = h->stamps;
-    hipError_t e = launch_step(h, a);
+    int mode = write_diag ? ebm::OUT_DIAG : ebm::OUT_STATE;
+    if (save) {
+        mode = ebm::OUT_SAVE;
+        a.sums = save->sums; a.sum_stride = save->sum_stride;
+        a.stage = save->stage; a.stage_var_stride = save->stage_var_stride; a.stage_offset = save->stage_offset;
+        std::memcpy(a.var_of, save->var_of, sizeof(a.var_of));
+    }
+    hipError_t e = launch_step(h, a, mode);
     if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     h->n_steps += 1;
     h->n_launches += 1;
     h->clock = step + 1;
     return EBM_OK;
 }
+
+// quantity index (ebm::MizQuantity / ClassicQuantity) of a public field id, -1 if the step kernels
+// do not produce it (the hidden warm start T0 is not a solution variable)
+int quantity_of(int model, int f) {
+    if (model == EBM_MODEL_MIZ) {
+        switch (f) {
+            case EBM_F_Ei: return ebm::Q_Ei;
+            case EBM_F_Ew: return ebm::Q_Ew;
+            case EBM_F_h: return ebm::Q_h;
+            case EBM_F_D: return ebm::Q_D;
+            case EBM_F_phi: return ebm::Q_phi;
+            case EBM_F_n: return ebm::Q_n;
+            case EBM_F_E: return ebm::Q_E;
+            case EBM_F_T: return ebm::Q_T;
+            case EBM_F_Ti: return ebm::Q_Ti;
+            case EBM_F_Tw: return ebm::Q_Tw;
+            default: return -1;
+        }
+    }
+    switch (f) {
+        case EBM_F_E: return ebm::QC_E;
+        case EBM_F_Tg: return ebm::QC_Tg;
+        case EBM_F_T: return ebm::QC_T;
+        case EBM_F_h: return ebm::QC_h;
+        default: return -1;
+    }
+}
+
+constexpr int kFusedTable = 16384;     // per-step scalars resident on the device at a time (512 KiB)
 
 }  // namespace
 
@@ -267,17 +314,17 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(EBM_ERR_NO_DEVICE, "ebm_create: no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(EBM_ERR_ARG, "ebm_create: device index out of range");
-    const char *geo = std::getenv("EBM_CELLS_PER_THREAD");   // tuning knob: "8" = 512 threads x 8 cells for long meridians
-    ebm::LaunchCfg cfg = ebm::choose_launch(nlat, geo && std::atoi(geo) == 8);
-    if (cfg.threads == 0) return fail(EBM_ERR_UNSUPPORTED, "ebm_create: nlat > 8192 is not supported");
+    ebm::LaunchCfg cfg = ebm::choose_launch(nlat);
+    if (cfg.threads == 0)
+        return fail(EBM_ERR_UNSUPPORTED, "ebm_create: nlat > 4096 is not supported (one workgroup owns a whole meridian)");
     HIPCHK(hipSetDevice(device));
     HIPCHK(ebm::prepare_kernels(cfg));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
     ebm_ctx *h = new ebm_ctx();
     h->model = model; h->grid = grid; h->nlat = nlat; h->ncol = ncol; h->device = device;
     h->dt = dt; h->cfg = cfg;
     {
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, device));
         h->num_cus = prop.multiProcessorCount;
         // a step of fewer than ~256K cells is launch-bound: replay graphs in ebm_run (EBM_GRAPH=0/1 overrides)
         const char *gv = std::getenv("EBM_GRAPH");
@@ -312,6 +359,9 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
     }
     if (e == hipSuccess) e = hipMalloc(&h->p_dev, sizeof(ebm::Params));
     if (e == hipSuccess) e = hipMemcpy(h->p_dev, &h->p, sizeof(ebm::Params), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = ebm::launch_derive_params(h->p_dev, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMalloc(&h->hm_dev, sizeof(double) * (size_t)ncol);
     if (e != hipSuccess) { ebm_destroy(h); return fail(EBM_ERR_HIP, std::string("state allocation: ") + hipGetErrorString(e)); }
     for (int f = 0; f < EBM_F_COUNT; ++f) {
         const int slot = slot_of(model, f);
@@ -336,6 +386,8 @@ int ebm_destroy(ebm_handle_t h) {
     if (h->p_dev) (void)hipFree(h->p_dev);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->sched_dev) (void)hipFree(h->sched_dev);
+    if (h->fused_sched) (void)hipFree(h->fused_sched);
+    if (h->hm_dev) (void)hipFree(h->hm_dev);
     if (h->amask) (void)hipFree(h->amask);
     if (h->fcol) (void)hipFree(h->fcol);
     if (h->fsched) (void)hipFree(h->fsched);
@@ -377,14 +429,32 @@ int ebm_hemispheric_mean(ebm_handle_t h, int field, double *out) {
     if (!h || !out) return fail(EBM_ERR_ARG, "ebm_hemispheric_mean: null argument");
     if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_hemispheric_mean: field not part of this model");
     HIPCHK(hipSetDevice(h->device));
-    double *dev = nullptr;
-    HIPCHK(hipMalloc(&dev, sizeof(double) * (size_t)h->ncol));
     hipError_t e = ebm::launch_hemispheric_mean(h->field[field], h->geom + (size_t)ebm::G_X * h->gstride, (int)h->pitch,
-                                                h->nlat, h->ncol, dev, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out, dev, sizeof(double) * (size_t)h->ncol, hipMemcpyDeviceToHost, h->stream);
+                                                h->nlat, h->ncol, h->hm_dev, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, h->hm_dev, sizeof(double) * (size_t)h->ncol, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(dev);
     if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("ebm_hemispheric_mean: ") + hipGetErrorString(e));
+    return EBM_OK;
+}
+
+int ebm_hemispheric_mean_device(ebm_handle_t h, int field, double *dev_out) {
+    if (!h || !dev_out) return fail(EBM_ERR_ARG, "ebm_hemispheric_mean_device: null argument");
+    if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_hemispheric_mean_device: field not part of this model");
+    HIPCHK(hipSetDevice(h->device));
+    hipError_t e = ebm::launch_hemispheric_mean(h->field[field], h->geom + (size_t)ebm::G_X * h->gstride, (int)h->pitch,
+                                                h->nlat, h->ncol, dev_out, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("ebm_hemispheric_mean_device: ") + hipGetErrorString(e));
+    return EBM_OK;
+}
+
+int ebm_get_field_device(ebm_handle_t h, int field, double *dev_out) {
+    if (!h || !dev_out) return fail(EBM_ERR_ARG, "ebm_get_field_device: null argument");
+    if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_get_field_device: field not part of this model");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpy2DAsync(dev_out, sizeof(double) * h->nlat, h->field[field], sizeof(double) * h->pitch,
+                            sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return EBM_OK;
 }
 
@@ -490,54 +560,75 @@ int ebm_run(ebm_handle_t h, long long first_step, int nsteps, const double *f_st
     return EBM_OK;
 }
 
+int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double *f_steps, int diag_last,
+                  int steps_per_launch) {
+    if (!h || nsteps < 0 || first_step < 0 || steps_per_launch < 1) return fail(EBM_ERR_ARG, "ebm_run_fused: bad argument");
+    if (h->ttab.empty()) return fail(EBM_ERR_ARG, "ebm_run_fused: call ebm_set_time_table first");
+    // the fused MIZ kernel keeps the whole state in registers: up to kFusedRegThreads threads per
+    // meridian (2048 cells); longer meridians are stepped one launch per step
+    if (steps_per_launch == 1 || (h->model == EBM_MODEL_MIZ && h->cfg.threads > ebm::kFusedRegThreads))
+        return ebm_run(h, first_step, nsteps, f_steps, diag_last);
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->fused_sched) HIPCHK(hipMalloc(&h->fused_sched, sizeof(ebm::StepSched) * kFusedTable));
+    const long long nt = (long long)h->ttab.size();
+    std::vector<ebm::StepSched> sched;
+    for (int s0 = 0; s0 < nsteps; s0 += kFusedTable) {
+        const int n = std::min(kFusedTable, nsteps - s0);
+        sched.resize(n);
+        for (int i = 0; i < n; ++i) {
+            const long long ti = (first_step + s0 + i) % nt;
+            sched[i].ct = h->ttab[ti];
+            sched[i].ct_next = h->ttab[(ti + 1) % nt];
+            sched[i].ft = f_steps ? f_steps[s0 + i] : 0.0;
+            sched[i].tyear = year_time(h, first_step + s0 + i);
+        }
+        // the launches of the previous batch still read the table: drain them before it is refilled
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(h->fused_sched, sched.data(), sizeof(ebm::StepSched) * (size_t)n, hipMemcpyHostToDevice));
+        for (int i = 0; i < n; i += steps_per_launch) {
+            ebm::StepArgs a = base_args(h);
+            a.sched = h->fused_sched;
+            a.slot = i;
+            a.nfused = std::min(steps_per_launch, n - i);
+            a.prefetch = 0;
+            a.write_diag = (diag_last && s0 + i + a.nfused == nsteps) ? 1 : 0;
+            hipError_t e = launch_step(h, a, ebm::OUT_LOOP);
+            if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
+            h->n_launches += 1;
+        }
+        h->n_steps += n;
+        h->clock = first_step + s0 + n;
+    }
+    return EBM_OK;
+}
+
 int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int lastonly,
                   int winter_inx, int summer_inx, int nvars, const int *fields, double *raw,
                   double *winter, double *summer, double *avg) {
-    if (!h || nt < 1 || dur < 1 || nvars < 0 || nvars > 12 || (nvars > 0 && !fields)) return fail(EBM_ERR_ARG, "ebm_integrate: bad argument");
+    if (!h || nt < 1 || dur < 1 || nvars < 0 || nvars > ebm::kMaxQuantities || (nvars > 0 && !fields))
+        return fail(EBM_ERR_ARG, "ebm_integrate: bad argument");
     if ((long long)h->ttab.size() != nt) return fail(EBM_ERR_ARG, "ebm_integrate: time table length must equal nt");
-    for (int v = 0; v < nvars; ++v)
-        if (!has_field(h, fields[v])) return fail(EBM_ERR_ARG, "ebm_integrate: field not part of this model");
+    SaveTarget save;
+    std::memset(save.var_of, -1, sizeof(save.var_of));
+    for (int v = 0; v < nvars; ++v) {
+        const int q = has_field(h, fields[v]) ? quantity_of(h->model, fields[v]) : -1;
+        if (q < 0) return fail(EBM_ERR_ARG, "ebm_integrate: not a solution variable of this model");
+        if (save.var_of[q] >= 0) return fail(EBM_ERR_ARG, "ebm_integrate: a variable is listed twice");
+        save.var_of[q] = (signed char)v;
+    }
     HIPCHK(hipSetDevice(h->device));
-    const size_t ncell = (size_t)h->ncol * h->nlat;          // packed cells per snapshot
+    const size_t ncell = (size_t)h->ncol * h->nlat;          // packed cells per snapshot (host side)
     const size_t npitch = (size_t)h->ncol * h->pitch;        // device elements per field
     const long long total = (long long)nt * dur;
     const long long nraw = lastonly ? nt : total;
-    // device staging for raw snapshots: [var][chunk][ncol][nlat]
+    // Device buffers: raw snapshots are staged as [var][chunk][ncol][pitch] and flushed to the host
+    // when the chunk is full; the annual-mean sums are [var][ncol*pitch] (pair-split layout).
     long long chunk = 0;
     double *stage = nullptr, *sums = nullptr, *mean = nullptr;
-    if (raw && nvars > 0) {
-        chunk = (long long)((256ull << 20) / (sizeof(double) * ncell * (size_t)nvars));
-        if (chunk < 1) chunk = 1;
-        if (chunk > nraw) chunk = nraw;
-        HIPCHK(hipMalloc(&stage, sizeof(double) * ncell * (size_t)nvars * (size_t)chunk));
-    }
-    if (avg && nvars > 0) {
-        HIPCHK(hipMalloc(&sums, sizeof(double) * npitch * (size_t)nvars));
-        HIPCHK(hipMemsetAsync(sums, 0, sizeof(double) * npitch * (size_t)nvars, h->stream));
-        HIPCHK(hipMalloc(&mean, sizeof(double) * npitch));
-    }
     auto cleanup = [&]() {
         if (stage) (void)hipFree(stage);
         if (sums) (void)hipFree(sums);
         if (mean) (void)hipFree(mean);
-    };
-    auto snapshot_to_host = [&](double *dst, const double *src_dev) -> hipError_t {
-        return hipMemcpy2DAsync(dst, sizeof(double) * h->nlat, src_dev, sizeof(double) * h->pitch,
-                                sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToHost, h->stream);
-    };
-    long long staged = 0, raw_base = 0;   // snapshots in the staging buffer; raw index of its first
-    auto flush = [&]() -> hipError_t {
-        if (!staged) return hipSuccess;
-        for (int v = 0; v < nvars; ++v) {
-            hipError_t e = hipMemcpyAsync(raw + ((size_t)v * nraw + raw_base) * ncell,
-                                          stage + (size_t)v * chunk * ncell,
-                                          sizeof(double) * ncell * (size_t)staged, hipMemcpyDeviceToHost, h->stream);
-            if (e != hipSuccess) return e;
-        }
-        hipError_t e = hipStreamSynchronize(h->stream);
-        raw_base += staged;
-        staged = 0;
-        return e;
     };
 #define EBM_TRY(expr)                                                                     \
     do {                                                                                  \
@@ -547,28 +638,55 @@ int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int la
             return fail(EBM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
         }                                                                                 \
     } while (0)
+    if (raw && nvars > 0) {
+        chunk = (long long)((256ull << 20) / (sizeof(double) * npitch * (size_t)nvars));
+        if (chunk < 1) chunk = 1;
+        if (chunk > nraw) chunk = nraw;
+        EBM_TRY(hipMalloc(&stage, sizeof(double) * npitch * (size_t)nvars * (size_t)chunk));
+    }
+    if (avg && nvars > 0) {
+        EBM_TRY(hipMalloc(&sums, sizeof(double) * npitch * (size_t)nvars));
+        EBM_TRY(hipMemsetAsync(sums, 0, sizeof(double) * npitch * (size_t)nvars, h->stream));
+        EBM_TRY(hipMalloc(&mean, sizeof(double) * npitch));
+    }
+    save.sums = sums;
+    save.sum_stride = (long long)npitch;
+    save.stage_var_stride = chunk * (long long)npitch;
+    auto snapshot_to_host = [&](double *dst, const double *src_dev) -> hipError_t {
+        return hipMemcpy2DAsync(dst, sizeof(double) * h->nlat, src_dev, sizeof(double) * h->pitch,
+                                sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToHost, h->stream);
+    };
+    long long staged = 0, raw_base = 0;   // snapshots in the staging buffer; raw index of its first
+    auto flush = [&]() -> hipError_t {
+        if (!staged) return hipSuccess;
+        for (int v = 0; v < nvars; ++v) {
+            // `staged` snapshots of ncol rows each: (staged * ncol) rows of nlat doubles, pitch apart
+            hipError_t e = hipMemcpy2DAsync(raw + ((size_t)v * nraw + raw_base) * ncell, sizeof(double) * h->nlat,
+                                            stage + (size_t)v * chunk * npitch, sizeof(double) * h->pitch,
+                                            sizeof(double) * h->nlat, (size_t)staged * h->ncol,
+                                            hipMemcpyDeviceToHost, h->stream);
+            if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipStreamSynchronize(h->stream);
+        raw_base += staged;
+        staged = 0;
+        return e;
+    };
     for (long long tinx = 1; tinx <= total; ++tinx) {              // 1-based, as the reference
         const long long ti = (tinx - 1) % nt + 1;
         const long long year = (tinx - 1) / nt + 1;                // ceil(st.T[tinx])
         const double f = f_steps ? f_steps[tinx - 1] : 0.0;
-        // savesol!, src/infrastructure.jl:549-591: annual-mean sums and raw snapshot in one launch
+        // savesol!, src/infrastructure.jl:549-591, from the step kernel's registers: the annual-mean
+        // sums on every step, the raw snapshot on the steps that are kept; the diagnostic FIELDS are
+        // only stored on steps whose snapshot is copied out of them (seasons) and on the last one
         const bool want_raw = stage && (!lastonly || tinx > total - nt);
-        // the diagnostic fields are only written on steps whose values are saved (or on the last one)
         const bool want_season = (ti == winter_inx && winter) || (ti == summer_inx && summer);
-        const int diag = (sums || want_raw || want_season || tinx == total) ? 1 : 0;
-        int rc = do_step(h, h->ttab[ti - 1], h->ttab[ti % nt], f, diag, tinx - 1);
+        const int diag = (want_season || tinx == total) ? 1 : 0;
+        save.stage = want_raw ? stage : nullptr;
+        save.stage_offset = staged * (long long)npitch;
+        int rc = do_step(h, h->ttab[ti - 1], h->ttab[ti % nt], f, diag, tinx - 1, (sums || want_raw) ? &save : nullptr);
         if (rc) { cleanup(); return rc; }
-        if (sums || want_raw) {
-            ebm::SaveArgs sa{};
-            sa.state = h->state; sa.fstride = h->fstride;
-            for (int v = 0; v < nvars; ++v) sa.slots[v] = slot_of(h->model, fields[v]);
-            sa.nvars = nvars; sa.pitch = (int)h->pitch; sa.nlat = h->nlat; sa.ncol = h->ncol;
-            sa.sums = sums; sa.sum_stride = (long long)npitch;
-            sa.stage = want_raw ? stage : nullptr;
-            sa.stage_var_stride = (long long)(chunk * (long long)ncell); sa.stage_index = staged;
-            EBM_TRY(ebm::launch_savesol(sa, h->stream));
-            if (want_raw && ++staged == chunk) EBM_TRY(flush());
-        }
+        if (want_raw && ++staged == chunk) EBM_TRY(flush());
         if (ti == winter_inx) {
             if (winter)
                 for (int v = 0; v < nvars; ++v)
@@ -580,7 +698,7 @@ int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int la
         } else if (ti == nt) {
             if (sums)
                 for (int v = 0; v < nvars; ++v) {
-                    EBM_TRY(ebm::launch_finish_mean(mean, sums + (size_t)v * npitch, (double)nt, npitch, h->stream));
+                    EBM_TRY(ebm::launch_finish_mean(mean, sums + (size_t)v * npitch, (double)nt, h->ncol, h->cfg.threads, h->stream));
                     EBM_TRY(snapshot_to_host(avg + ((size_t)v * dur + (year - 1)) * ncell, mean));
                     EBM_TRY(hipStreamSynchronize(h->stream));
                 }

@@ -108,6 +108,17 @@ class Engine:
         check(self.lib.ebm_hemispheric_mean(self._h, FIELD[name], dptr(out)), "ebm_hemispheric_mean")
         return out
 
+    def hemispheric_mean_device(self, name: str, dev_ptr: int):
+        """Same reduction, result left on the device at ``dev_ptr`` (``ncol`` doubles, e.g. the
+        ``data_ptr()`` of a torch tensor on this engine's device)."""
+        check(self.lib.ebm_hemispheric_mean_device(self._h, FIELD[name], C.c_void_p(dev_ptr)),
+              "ebm_hemispheric_mean_device")
+
+    def get_field_device(self, name: str, dev_ptr: int):
+        """Device-to-device copy of a field, packed [ncol][nlat], to ``dev_ptr``."""
+        check(self.lib.ebm_get_field_device(self._h, FIELD[name], C.c_void_p(dev_ptr)),
+              "ebm_get_field_device")
+
     def field_device_ptr(self, name: str):
         p, pitch = C.c_void_p(), C.c_longlong()
         check(self.lib.ebm_field_device_ptr(self._h, FIELD[name], C.byref(p), C.byref(pitch)),
@@ -143,10 +154,18 @@ class Engine:
     def step(self, ct: float, ct_next: float, f: float, write_diag: bool = True):
         check(self.lib.ebm_step(self._h, ct, ct_next, f, int(write_diag)), "ebm_step")
 
-    def run(self, first_step: int, nsteps: int, f_steps=None, diag_last: bool = True):
+    def run(self, first_step: int, nsteps: int, f_steps=None, diag_last: bool = True,
+            steps_per_launch: int = 1):
+        """``nsteps`` steps from global step ``first_step``.  ``steps_per_launch`` = K > 1 fuses K
+        consecutive steps into one launch (ebm_run_fused; bit-identical results, no per-step
+        output in between)."""
         a = None if f_steps is None else as_f64(f_steps, (nsteps,))
-        check(self.lib.ebm_run(self._h, int(first_step), int(nsteps), dptr(a), int(diag_last)),
-              "ebm_run")
+        if steps_per_launch > 1:
+            check(self.lib.ebm_run_fused(self._h, int(first_step), int(nsteps), dptr(a), int(diag_last),
+                                         int(steps_per_launch)), "ebm_run_fused")
+        else:
+            check(self.lib.ebm_run(self._h, int(first_step), int(nsteps), dptr(a), int(diag_last)),
+                  "ebm_run")
 
     def integrate(self, nt, dur, f_steps, lastonly, winter_inx, summer_inx, names,
                   want_raw=True, want_seasonal=True, want_avg=True):
@@ -158,8 +177,9 @@ class Engine:
         nraw = nt if lastonly else nt * dur
         f = None if f_steps is None else as_f64(f_steps, (nt * dur,))
         raw = np.empty((nv, nraw, self.ncol, self.nlat)) if want_raw else None
-        mk = (lambda: np.full((nv, dur, self.ncol, self.nlat), np.nan)) if want_seasonal else (lambda: None)
-        winter, summer, avg = mk(), mk(), (mk() if want_avg else None)
+        def mk(wanted):
+            return np.full((nv, dur, self.ncol, self.nlat), np.nan) if wanted else None
+        winter, summer, avg = mk(want_seasonal), mk(want_seasonal), mk(want_avg)
         check(self.lib.ebm_integrate(self._h, nt, dur, dptr(f), int(lastonly), int(winter_inx),
                                      int(summer_inx), nv, fields, dptr(raw), dptr(winter),
                                      dptr(summer), dptr(avg)), "ebm_integrate")

@@ -48,6 +48,7 @@ class EnsembleRun:
         if forcings is not None:
             self.ncol = len(forcings)
         self.st = st
+        self.device = int(device)
         self.engine = Engine(model, st.grid_kind, st.x, param_vector(par, default_parval), st.dt,
                              self.ncol, device)
         for k, v in init.items():
@@ -62,17 +63,34 @@ class EnsembleRun:
             self.engine.set_column_schedules(forcings)
         self.step_index = 0
 
-    def run(self, nsteps, forcing=None, diag_last=True):
-        """Advance ``nsteps`` steps (one launch per step); ``forcing`` is a Forcing or None."""
+    def run(self, nsteps, forcing=None, diag_last=True, steps_per_launch=1):
+        """Advance ``nsteps`` steps; ``forcing`` is a Forcing or None.  One launch per step unless
+        ``steps_per_launch`` > 1 (fused stepping, same results)."""
         f = None
         if forcing is not None:
             T = (np.arange(self.step_index, self.step_index + nsteps) + 0.5) * self.st.dt
             f = np.array([forcing(float(t)) for t in T])
-        self.engine.run(self.step_index, nsteps, f, diag_last)
+        self.engine.run(self.step_index, nsteps, f, diag_last, steps_per_launch)
         self.step_index += nsteps
 
     def state(self, names=None):
         return self.engine.get_state(names)
+
+    def hemispheric_mean_tensor(self, name):
+        """Per-column hemispheric mean (reference src/utilities.jl:397-403) as a torch tensor ON THE
+        DEVICE — reduced there by ebm_hemispheric_mean_device, never staged through the host — ready
+        to be gathered over RCCL (gather_columns)."""
+        import torch
+        out = torch.empty(self.ncol, dtype=torch.float64, device=torch.device("cuda", self.device))
+        self.engine.hemispheric_mean_device(name, out.data_ptr())
+        return out
+
+    def field_tensor(self, name):
+        """A packed [ncol, nlat] device tensor copy of a field (device-to-device)."""
+        import torch
+        out = torch.empty((self.ncol, self.st.nx), dtype=torch.float64, device=torch.device("cuda", self.device))
+        self.engine.get_field_device(name, out.data_ptr())
+        return out
 
     def close(self):
         self.engine.close()
@@ -107,27 +125,44 @@ def broadcast_inputs(arrays: dict | None, dist=None, device=None, src: int = 0) 
     return out
 
 
-def gather_columns(local: np.ndarray, ncol_total: int, dist=None, device=None) -> np.ndarray | None:
-    """Gather per-column data ([ncol_local, ...]) from all ranks to rank 0 (I/O only).
+def _backend(dist) -> str:
+    try:
+        return str(dist.get_backend())
+    except Exception:
+        return ""
 
-    Uses torch.distributed all_gather on equal-size padded blocks; returns the [ncol_total, ...]
-    array on rank 0 and None elsewhere.  With dist=None (single process) returns ``local``."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return local
+
+def gather_columns(local, ncol_total: int, dist=None, device=None, dst: int = 0):
+    """Gather per-column data ([ncol_local, ...]) from all ranks to rank ``dst`` (I/O only).
+
+    ``local`` is a NumPy array or a torch tensor.  With the "nccl" backend (= RCCL on ROCm) the
+    payload stays on the device end to end: a device tensor (e.g. from
+    ``EnsembleRun.hemispheric_mean_tensor`` / ``field_tensor``) is gathered with ``dist.gather`` —
+    point-to-point sends to ``dst`` only, 1/world_size of an all-gather's traffic — and copied to the
+    host once, on ``dst``.  With "gloo" (CPU tests) host tensors are gathered.  Returns the
+    [ncol_total, ...] NumPy array on ``dst`` and None elsewhere.  With dist=None (single process)
+    returns ``local`` as a NumPy array."""
+    import_torch = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    if not import_torch:
+        return local.cpu().numpy() if hasattr(local, "cpu") else local
     import torch
     ws, rank = dist.get_world_size(), dist.get_rank()
-    width = -(-ncol_total // ws)
-    pad = np.zeros((width,) + local.shape[1:], dtype=np.float64)
-    pad[: local.shape[0]] = local
-    t = torch.from_numpy(pad)
-    if device is not None:
-        t = t.to(device)
-    outs = [torch.empty_like(t) for _ in range(ws)]
-    dist.all_gather(outs, t)
-    if rank != 0:
+    t = local if isinstance(local, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local, dtype=np.float64))
+    if _backend(dist) == "nccl":
+        if t.device.type == "cpu":
+            t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    else:
+        t = t.cpu()
+    width = -(-ncol_total // ws)                      # block sizes differ by at most one column: pad
+    if t.shape[0] < width:
+        t = torch.cat([t, torch.zeros((width - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)])
+    t = t.contiguous()
+    outs = [torch.empty_like(t) for _ in range(ws)] if rank == dst else None
+    dist.gather(t, outs, dst=dst)
+    if rank != dst:
         return None
     parts = []
     for r in range(ws):
         sl = shard_columns(ncol_total, ws, r)
-        parts.append(outs[r].cpu().numpy()[: sl.stop - sl.start])
-    return np.concatenate(parts, axis=0)
+        parts.append(outs[r][: sl.stop - sl.start])
+    return torch.cat(parts, dim=0).cpu().numpy()

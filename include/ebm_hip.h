@@ -74,7 +74,8 @@ enum ebm_field {
 /* ---- lifetime ------------------------------------------------------------------------ */
 
 /* Create a stepping context on HIP device `device` for `ncol` independent meridians of
- * `nlat` cells.  x[nlat] is st.x, params[EBM_P_COUNT] the parameter values (entries a model
+ * `nlat` cells (2 <= nlat <= 4096: one workgroup owns a whole meridian; longer ones are refused with
+ * EBM_ERR_UNSUPPORTED).  x[nlat] is st.x, params[EBM_P_COUNT] the parameter values (entries a model
  * does not use are ignored), dt = st.dt.  All state starts at zero (as the reference's T0
  * warm start does).  Fails with EBM_ERR_NO_DEVICE when no GPU is present. */
 int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const double *x,
@@ -92,6 +93,10 @@ int ebm_get_field(ebm_handle_t h, int field, double *host);
  * reference's summation order (bit-identical): out[ncol] on the host.  Ensemble diagnostics are
  * O(columns) instead of O(state).  Synchronous. */
 int ebm_hemispheric_mean(ebm_handle_t h, int field, double *out);
+/* Device-to-device variants for callers that keep their own device buffers (e.g. the payload of an
+ * RCCL gather): dev_out[ncol] / dev_out[ncol][nlat] packed, on the handle's device.  Synchronous. */
+int ebm_hemispheric_mean_device(ebm_handle_t h, int field, double *dev_out);
+int ebm_get_field_device(ebm_handle_t h, int field, double *dev_out);
 /* Device pointer of a field and its row pitch in elements (>= nlat), for zero-copy users
  * (e.g. a torch tensor view).  The pointer stays valid until ebm_destroy. */
 int ebm_field_device_ptr(ebm_handle_t h, int field, double **dptr, long long *pitch);
@@ -129,13 +134,25 @@ int ebm_step(ebm_handle_t h, double cos2pit, double cos2pit_next, double f, int 
 int ebm_run(ebm_handle_t h, long long first_step, int nsteps, const double *f_steps,
             int diag_last);
 
+/* The same nsteps steps with `steps_per_launch` (K) consecutive steps fused into one kernel launch:
+ * the time loop of integrate (src/infrastructure.jl:630-634) for callers that need no per-step
+ * output.  Between the steps of a launch the whole state stays in registers; the per-step scalars
+ * come from a device table.  Results are bit-identical to ebm_run.  Meridians of more than 2048 cells
+ * have no fused kernel: there K is ignored and every step is its own launch (ebm_get_counters
+ * reports the launches actually made).  Asynchronous. */
+int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double *f_steps,
+                  int diag_last, int steps_per_launch);
+
 /* integrate + savesol! (src/infrastructure.jl:549-591, 615-636) with state resident on the
  * device: runs nt*dur steps from the current state.  `fields[nvars]` selects the saved
  * variables; outputs are host buffers (any may be NULL to skip):
  *   raw    [nvars][nraw][ncol][nlat]   nraw = lastonly ? nt : nt*dur
  *   winter, summer, avg  [nvars][dur][ncol][nlat]
  * winter_inx/summer_inx are the 1-based in-year indices st.winter.inx / st.summer.inx.
- * f_steps[nt*dur] as in ebm_run.  Synchronous. */
+ * f_steps[nt*dur] as in ebm_run.  `fields` must be solution variables (not the hidden EBM_F_T0),
+ * each at most once.  savesol! runs inside the step kernel: one launch per step, the annual-mean
+ * sums (crossmean, src/utilities.jl:390-395: summed per cell in step order) and the raw snapshot
+ * are taken from the step's registers.  Synchronous. */
 int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int lastonly,
                   int winter_inx, int summer_inx, int nvars, const int *fields, double *raw,
                   double *winter, double *summer, double *avg);

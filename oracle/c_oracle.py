@@ -23,13 +23,28 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(_dp)
 
 
+class _Prefixed:
+    """lib.ebmo_xyz -> the build's own prefix (ebmo_ for fp64, ebmol_ for the extended build)."""
+
+    def __init__(self, lib, prefix):
+        self._lib, self._prefix = lib, prefix
+
+    def __getattr__(self, name):
+        return getattr(self._lib, self._prefix + name[len("ebmo_"):] if name.startswith("ebmo_") else name)
+
+
 class COracle:
-    def __init__(self, openmp=False):
-        name = "libebm_oracle_omp.so" if openmp else "libebm_oracle.so"
+    """fp64 C oracle (default), its OpenMP build (cpu_baseline), or — ``extended=True`` — the same
+    source evaluated in 80-bit extended precision between fp64 inputs and outputs (a rounding-error
+    measuring stick, see the header of ebm_oracle.c)."""
+
+    def __init__(self, openmp=False, extended=False):
+        name = "libebm_oracle_ld.so" if extended else ("libebm_oracle_omp.so" if openmp else "libebm_oracle.so")
         path = os.path.join(_HERE, name)
         if not os.path.exists(path):
             build()
-        self.lib = C.CDLL(path)
+        self.extended = extended
+        self.lib = _Prefixed(C.CDLL(path), "ebmol_" if extended else "ebmo_")
         self.lib.ebmo_max_threads.restype = C.c_int
 
     def max_threads(self):

@@ -14,8 +14,26 @@
  * so no FMA contraction or re-association happens.  Citations are to /root/reference.
  *
  * Layout: every state array is [ncol][nx], latitude contiguous (one Julia Vec per column).
+ *
+ * Two builds of this one source (oracle/Makefile): `real` = double, entry points ebmo_* — THE oracle;
+ * and -DEBMO_LONG: `real` = long double (x87 80-bit), entry points ebmol_* — the same formulas, the
+ * same fp64 inputs, outputs rounded to fp64 once at the end of a run, ~2000x less rounding error in
+ * between.  The extended build is a measuring stick for rounding error only (how far the fp64 oracle
+ * and the GPU each are from the exactly-evaluated discrete model, tests/test_error_budget.py); it is
+ * not a second opinion on the transcription.
  */
 #include <math.h>
+#ifdef EBMO_LONG
+typedef long double real;
+#define EBMO(name) ebmol_##name
+#define R_POW powl
+#define R_COPYSIGN copysignl
+#else
+typedef double real;
+#define EBMO(name) ebmo_##name
+#define R_POW pow
+#define R_COPYSIGN copysign
+#endif
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -28,24 +46,24 @@ enum { P_D, P_A, P_B, P_cw, P_S0, P_S1, P_S2, P_a0, P_a2, P_ai, P_Fb, P_k, P_Lf,
 #define MAX_NEWTON 50
 
 /* Julia min(::Float64, ::Float64): NaN-propagating, -0.0 < +0.0 */
-static inline double jl_min(double x, double y) {
-    double diff = x - y;
-    double am = signbit(diff) ? x : y;
+static inline real jl_min(real x, real y) {
+    real diff = x - y;
+    real am = signbit(diff) ? x : y;
     return (isnan(x) || isnan(y)) ? diff : am;
 }
 /* Julia clamp(x, lo, hi) = ifelse(x > hi, hi, ifelse(x < lo, lo, x)) */
-static inline double jl_clamp(double x, double lo, double hi) {
+static inline real jl_clamp(real x, real lo, real hi) {
     return x > hi ? hi : (x < lo ? lo : x);
 }
 /* Julia *(x::Float64, b::Bool) */
-static inline double bool_mul(double x, int b) { return b ? x : copysign(0.0, x); }
+static inline real bool_mul(real x, int b) { return b ? x : R_COPYSIGN((real)0.0, x); }
 
 /* ---- diffusion geometry, src/infrastructure.jl:477-492 (identity), :509-518 (other) ---- */
 typedef struct {
     int kind, nx;              /* kind 0 = identity, 1 = non-uniform ("sin") */
-    double D;
-    double *c0, *c1, *c2, *c3, *c4; /* identity: sub, diag, sup ; else mph, mmh, dxp, dxm, w */
-    double *lo, *di, *up;      /* plain tridiagonal coefficients (Jacobian assembly only) */
+    real D;
+    real *c0, *c1, *c2, *c3, *c4; /* identity: sub, diag, sup ; else mph, mmh, dxp, dxm, w */
+    real *lo, *di, *up;      /* plain tridiagonal coefficients (Jacobian assembly only) */
 } Geom;
 
 static void geom_free(Geom *g) {
@@ -53,42 +71,42 @@ static void geom_free(Geom *g) {
     free(g->lo); free(g->di); free(g->up);
 }
 
-static void geom_init(Geom *g, int kind, int nx, const double *x, double D) {
+static void geom_init(Geom *g, int kind, int nx, const real *x, real D) {
     g->kind = kind; g->nx = nx; g->D = D;
-    size_t nb = sizeof(double) * (size_t)nx;
+    size_t nb = sizeof(real) * (size_t)nx;
     g->c0 = calloc(1, nb); g->c1 = calloc(1, nb); g->c2 = calloc(1, nb);
     g->c3 = calloc(1, nb); g->c4 = calloc(1, nb);
     g->lo = calloc(1, nb); g->di = calloc(1, nb); g->up = calloc(1, nb);
     if (kind == 0) {
-        double dx = 1.0 / nx;
-        double *lam = calloc(1, nb);
+        real dx = 1.0 / nx;
+        real *lam = calloc(1, nb);
         for (int i = 1; i < nx; ++i) {
-            double xb = (double)i / nx;
+            real xb = (real)i / nx;
             lam[i - 1] = (1.0 - xb * xb) / (dx * dx);
         }
         for (int k = 0; k < nx; ++k) {
-            double sub = k > 0 ? lam[k - 1] : 0.0;
-            double sup = k < nx - 1 ? lam[k] : 0.0;
-            double l1 = k > 0 ? -lam[k - 1] : 0.0;
-            double l2 = k < nx - 1 ? -lam[k] : 0.0;
-            double l3 = (-l1) - l2;
+            real sub = k > 0 ? lam[k - 1] : 0.0;
+            real sup = k < nx - 1 ? lam[k] : 0.0;
+            real l1 = k > 0 ? -lam[k - 1] : 0.0;
+            real l2 = k < nx - 1 ? -lam[k] : 0.0;
+            real l3 = (-l1) - l2;
             g->c0[k] = D * sub; g->c1[k] = D * (-l3); g->c2[k] = D * sup;
             g->lo[k] = g->c0[k]; g->di[k] = g->c1[k]; g->up[k] = g->c2[k];
         }
         free(lam);
     } else {
         for (int k = 0; k < nx; ++k) {
-            double xk = x[k];
-            double xm = k > 0 ? x[k - 1] : -x[0];
-            double xp = k < nx - 1 ? x[k + 1] : 2.0 - x[nx - 1];
-            double xxph = (xp + xk) / 2.0, xxmh = (xk + xm) / 2.0;
+            real xk = x[k];
+            real xm = k > 0 ? x[k - 1] : -x[0];
+            real xp = k < nx - 1 ? x[k + 1] : 2.0 - x[nx - 1];
+            real xxph = (xp + xk) / 2.0, xxmh = (xk + xm) / 2.0;
             g->c0[k] = 1.0 - xxph * xxph;
             g->c1[k] = 1.0 - xxmh * xxmh;
             g->c2[k] = xp - xk;
             g->c3[k] = xk - xm;
             g->c4[k] = xxph - xxmh;
-            double up = D * g->c0[k] / (g->c2[k] * g->c4[k]);
-            double lo = D * g->c1[k] / (g->c3[k] * g->c4[k]);
+            real up = D * g->c0[k] / (g->c2[k] * g->c4[k]);
+            real lo = D * g->c1[k] / (g->c3[k] * g->c4[k]);
             if (k == nx - 1) up = 0.0;
             if (k == 0) lo = 0.0;
             g->lo[k] = lo; g->up[k] = up; g->di[k] = -(lo + up);
@@ -97,27 +115,27 @@ static void geom_init(Geom *g, int kind, int nx, const double *x, double D) {
 }
 
 /* base + D d/dx[(1-x^2) d temp/dx] at cell k; src/infrastructure.jl:495-497 and :521-524 */
-static inline double diffusion_add(const Geom *g, double base, const double *temp, int k) {
+static inline real diffusion_add(const Geom *g, real base, const real *temp, int k) {
     int nx = g->nx;
     if (g->kind == 0) {
-        double y = 0.0;
+        real y = 0.0;
         if (k > 0) y = y + g->c0[k] * temp[k - 1];
         y = y + g->c1[k] * temp[k];
         if (k < nx - 1) y = y + g->c2[k] * temp[k + 1];
         return base + y;
     }
-    double dTp = k < nx - 1 ? temp[k + 1] - temp[k] : 0.0;
-    double dTm = k > 0 ? temp[k] - temp[k - 1] : 0.0;
+    real dTp = k < nx - 1 ? temp[k + 1] - temp[k] : 0.0;
+    real dTm = k > 0 ? temp[k] - temp[k - 1] : 0.0;
     return base + (g->D * ((g->c0[k] * dTp) / g->c2[k] - (g->c1[k] * dTm) / g->c3[k])) / g->c4[k];
 }
 
 /* Thomas algorithm, same operation order as oracle/ebm_oracle.py:thomas */
-static void thomas(int n, const double *a, const double *b, const double *c, const double *d,
-                   double *cp, double *dp, double *xs) {
+static void thomas(int n, const real *a, const real *b, const real *c, const real *d,
+                   real *cp, real *dp, real *xs) {
     cp[0] = c[0] / b[0];
     dp[0] = d[0] / b[0];
     for (int i = 1; i < n; ++i) {
-        double den = b[i] - a[i] * cp[i - 1];
+        real den = b[i] - a[i] * cp[i - 1];
         cp[i] = c[i] / den;
         dp[i] = (d[i] - a[i] * dp[i - 1]) / den;
     }
@@ -125,21 +143,21 @@ static void thomas(int n, const double *a, const double *b, const double *c, con
     for (int i = n - 2; i >= 0; --i) xs[i] = dp[i] - cp[i] * xs[i + 1];
 }
 
-void ebmo_thomas(int n, const double *a, const double *b, const double *c, const double *d,
-                 double *xs) {
-    double *cp = malloc(sizeof(double) * n), *dp = malloc(sizeof(double) * n);
+static void thomas_export(int n, const real *a, const real *b, const real *c, const real *d,
+                 real *xs) {
+    real *cp = malloc(sizeof(real) * n), *dp = malloc(sizeof(real) * n);
     thomas(n, a, b, c, d, cp, dp, xs);
     free(cp); free(dp);
 }
 
 typedef struct {
-    double *Tw, *Ti, *hp, *dd, *r, *rhs, *g, *a, *b, *c, *d, *cp, *dp, *v, *tb;
+    real *Tw, *Ti, *hp, *dd, *r, *rhs, *g, *a, *b, *c, *d, *cp, *dp, *v, *tb;
     unsigned char *s;
 } Work;
 
 static void work_init(Work *w, int nx) {
-    size_t nb = sizeof(double) * (size_t)nx;
-    double **ps[] = {&w->Tw, &w->Ti, &w->hp, &w->dd, &w->r, &w->rhs, &w->g, &w->a, &w->b,
+    size_t nb = sizeof(real) * (size_t)nx;
+    real **ps[] = {&w->Tw, &w->Ti, &w->hp, &w->dd, &w->r, &w->rhs, &w->g, &w->a, &w->b,
                      &w->c, &w->d, &w->cp, &w->dp, &w->v, &w->tb};
     for (size_t i = 0; i < sizeof(ps) / sizeof(ps[0]); ++i) *ps[i] = malloc(nb);
     w->s = malloc((size_t)nx);
@@ -150,23 +168,23 @@ static void work_free(Work *w) {
     free(w->tb); free(w->s);
 }
 
-static inline double insolation(const double *p, double x, double ct) {
+static inline real insolation(const real *p, real x, real ct) {
     /* src/miz.jl:11 */
     return p[P_S0] - p[P_S1] * x * ct - p[P_S2] * (x * x);
 }
 
 /* One MIZ step for one column; src/miz.jl:150-196.  Returns number of tridiagonal solves,
  * negative if the active-set iteration hit MAX_NEWTON. */
-static int miz_step_col(const Geom *g, const double *p, int nx, const double *x, double dt,
-                        double ct, double f, double *Ei, double *Ew, double *h, double *D,
-                        double *phi, double *T0, double *Tw_o, double *Ti_o, double *n_o,
-                        double *E_o, double *T_o, Work *w) {
-    const double Tm = p[P_Tm], cw = p[P_cw], A = p[P_A], B = p[P_B], ai = p[P_ai];
-    const double Lf = p[P_Lf], alpha = p[P_alpha], hmin = p[P_hmin], Dmin = p[P_Dmin];
-    const double Dmax = p[P_Dmax], Fb = p[P_Fb];
+static int miz_step_col(const Geom *g, const real *p, int nx, const real *x, real dt,
+                        real ct, real f, real *Ei, real *Ew, real *h, real *D,
+                        real *phi, real *T0, real *Tw_o, real *Ti_o, real *n_o,
+                        real *E_o, real *T_o, Work *w) {
+    const real Tm = p[P_Tm], cw = p[P_cw], A = p[P_A], B = p[P_B], ai = p[P_ai];
+    const real Lf = p[P_Lf], alpha = p[P_alpha], hmin = p[P_hmin], Dmin = p[P_Dmin];
+    const real Dmax = p[P_Dmax], Fb = p[P_Fb];
     /* water temperature, src/miz.jl:30,157 */
     for (int k = 0; k < nx; ++k) {
-        double tw = Tm + Ew[k] / ((1.0 - phi[k]) * cw);
+        real tw = Tm + Ew[k] / ((1.0 - phi[k]) * cw);
         w->Tw[k] = isnan(tw) ? 0.0 : tw;
     }
     /* solveTi, src/miz.jl:47-68 — active-set Newton on the piecewise-linear T0eq (:33-45) */
@@ -177,7 +195,7 @@ static int miz_step_col(const Geom *g, const double *p, int nx, const double *x,
         w->s[k] = T0[k] < Tm;
     }
     for (int k = 0; k < nx; ++k) {
-        double rm = k > 0 ? w->r[k - 1] : 0.0, rp = k < nx - 1 ? w->r[k + 1] : 0.0;
+        real rm = k > 0 ? w->r[k - 1] : 0.0, rp = k < nx - 1 ? w->r[k + 1] : 0.0;
         w->rhs[k] = ai * insolation(p, x[k], ct) - A + (g->lo[k] * rm + g->di[k] * w->r[k] + g->up[k] * rp) + f;
         w->d[k] = -w->rhs[k];
     }
@@ -186,7 +204,7 @@ static int miz_step_col(const Geom *g, const double *p, int nx, const double *x,
         ++nit;
         for (int k = 0; k < nx; ++k) w->g[k] = w->s[k] ? phi[k] : 0.0;
         for (int k = 0; k < nx; ++k) {
-            double gm = k > 0 ? w->g[k - 1] : 0.0, gp = k < nx - 1 ? w->g[k + 1] : 0.0;
+            real gm = k > 0 ? w->g[k - 1] : 0.0, gp = k < nx - 1 ? w->g[k + 1] : 0.0;
             w->a[k] = g->lo[k] * gm;
             w->c[k] = g->up[k] * gp;
             w->b[k] = g->di[k] * w->g[k] - w->dd[k];
@@ -202,70 +220,70 @@ static int miz_step_col(const Geom *g, const double *p, int nx, const double *x,
     }
     for (int k = 0; k < nx; ++k) {
         T0[k] = w->v[k] + Tm;
-        double ti = jl_min(T0[k], Tm);
+        real ti = jl_min(T0[k], Tm);
         w->Ti[k] = (h[k] == 0.0) ? 0.0 : ti;
         w->tb[k] = w->Ti[k] * phi[k] + (1.0 - phi[k]) * w->Tw[k];           /* Tbar :21-26 */
     }
-    const double Tm_pow = pow(Tm, p[P_m2]);
-    const double c_latmelt = -M_PI / 2.0 * alpha;
-    const double c_dn = Lf * alpha * (Dmin * Dmin) * hmin;
-    const double c_weld = p[P_kappa] * alpha / 4.0;
-    const double c_ht = -1.0 / Lf;
-    const double two_rl = 2.0 * p[P_rl];
+    const real Tm_pow = R_POW(Tm, p[P_m2]);
+    const real c_latmelt = -M_PI / 2.0 * alpha;
+    const real c_dn = Lf * alpha * (Dmin * Dmin) * hmin;
+    const real c_weld = p[P_kappa] * alpha / 4.0;
+    const real c_ht = -1.0 / Lf;
+    const real two_rl = 2.0 * p[P_rl];
     for (int k = 0; k < nx; ++k) {
-        const double xk = x[k], ph = phi[k], hk = h[k], Dk = D[k], Tw = w->Tw[k], Ti = w->Ti[k];
+        const real xk = x[k], ph = phi[k], hk = h[k], Dk = D[k], Tw = w->Tw[k], Ti = w->Ti[k];
         /* num :83-87 */
-        double n = ph / (alpha * (Dk * Dk));
+        real n = ph / (alpha * (Dk * Dk));
         if (Dk == 0.0) n = 0.0;
         /* vert_flux :96-101 */
-        double S = insolation(p, xk, ct);
-        double L = A + B * (w->tb[k] - Tm);
-        double sol_i = 0.0 + ai * S;
-        double sol_w = 0.0 + (p[P_a0] - p[P_a2] * (xk * xk)) * S;
-        double dif = diffusion_add(g, 0.0, w->tb, k);
-        double Fvi = sol_i - L + dif + Fb + f;
-        double Fvw = sol_w - L + dif + Fb + f;
+        real S = insolation(p, xk, ct);
+        real L = A + B * (w->tb[k] - Tm);
+        real sol_i = 0.0 + ai * S;
+        real sol_w = 0.0 + (p[P_a0] - p[P_a2] * (xk * xk)) * S;
+        real dif = diffusion_add(g, 0.0, w->tb, k);
+        real Fvi = sol_i - L + dif + Fb + f;
+        real Fvw = sol_w - L + dif + Fb + f;
         /* lat_flux :103-107, wlat :71 */
-        double wl = p[P_m1] * (Tw - Tm_pow);
-        double Flat = ph * hk * Lf * wl * M_PI / (alpha * Dk);
+        real wl = p[P_m1] * (Tw - Tm_pow);
+        real Flat = ph * hk * Lf * wl * M_PI / (alpha * Dk);
         if (Dk == 0.0) Flat = 0.0;
         /* forward Euler + redistribution :166-170, :109-117 */
-        double rEi = Ei[k] + (ph * Fvi + Flat) * dt;
-        double rEw = Ew[k] + ((1.0 - ph) * Fvw - Flat) * dt;
-        double cEi = jl_clamp(rEi, -INFINITY, 0.0);
-        double cEw = jl_clamp(rEw, 0.0, INFINITY);
-        double psiEidt = rEi - cEi, psiEwdt = rEw - cEw;
-        double Ei_n = cEi + psiEwdt, Ew_n = cEw + psiEidt;
+        real rEi = Ei[k] + (ph * Fvi + Flat) * dt;
+        real rEw = Ew[k] + ((1.0 - ph) * Fvw - Flat) * dt;
+        real cEi = jl_clamp(rEi, -INFINITY, 0.0);
+        real cEw = jl_clamp(rEw, 0.0, INFINITY);
+        real psiEidt = rEi - cEi, psiEwdt = rEw - cEw;
+        real Ei_n = cEi + psiEwdt, Ew_n = cEw + psiEidt;
         /* area_lead :90-93 */
-        double Dr = Dk + two_rl;
-        double ring = alpha * n * (Dr * Dr - Dk * Dk);
-        double Al = jl_min(ring, 1.0 - ph);
+        real Dr = Dk + two_rl;
+        real ring = alpha * n * (Dr * Dr - Dk * Dk);
+        real Al = jl_min(ring, 1.0 - ph);
         /* split_psiEw :120-125 on psiEwdt/dt (:173) */
-        double psi = psiEwdt / dt;
-        double Ql = Al / (1.0 - ph) * psi;
+        real psi = psiEwdt / dt;
+        real Ql = Al / (1.0 - ph) * psi;
         if (ph == 1.0) Ql = 0.0;
-        double Qp = psi - Ql;
+        real Qp = psi - Ql;
         /* psinplus :127, :174 */
-        double dn = dt * (-Qp / c_dn);
+        real dn = dt * (-Qp / c_dn);
         /* D_t :140-146 */
-        double lat_melt = c_latmelt * wl;
-        double lat_grow = -Dk / (2.0 * Lf * hk * ph) * Ql;
-        double weld = c_weld * ph * (Dk * Dk * Dk);
+        real lat_melt = c_latmelt * wl;
+        real lat_grow = -Dk / (2.0 * Lf * hk * ph) * Ql;
+        real weld = c_weld * ph * (Dk * Dk * Dk);
         if (hk == 0.0) lat_grow = 0.0;
-        double rD = Dk + (lat_melt + lat_grow + weld) * dt;
+        real rD = Dk + (lat_melt + lat_grow + weld) * dt;
         /* average :129-134, clamp!, zeroref! (:176-178) */
-        double total = n + dn;
-        double D_n = (n * rD + dn * Dmin) / total;
+        real total = n + dn;
+        real D_n = (n * rD + dn * Dmin) / total;
         if (total == 0.0) D_n = 0.0;
         D_n = jl_clamp(D_n, Dmin, Dmax);
         if (Ei_n == 0.0) D_n = 0.0;
         /* thickness :179-181 */
-        double rh = hk + (c_ht * Fvi) * dt;
+        real rh = hk + (c_ht * Fvi) * dt;
         rh = jl_clamp(rh, 0.0, INFINITY);
-        double h_n = (n * rh + dn * hmin) / total;
+        real h_n = (n * rh + dn * hmin) / total;
         if (total == 0.0) h_n = 0.0;
         /* concentration :74-80 */
-        double phi_n = -Ei_n / (Lf * h_n);
+        real phi_n = -Ei_n / (Lf * h_n);
         if (h_n == 0.0) phi_n = 0.0;
         if (phi_n > 1.0) phi_n = 1.0;
         if (h_n == 0.0) Ei_n = 0.0;                                        /* :185 */
@@ -282,10 +300,10 @@ static int miz_step_col(const Geom *g, const double *p, int nx, const double *x,
 /* nsteps MIZ steps on ncol independent columns.  ct[s] = cos(2.0*pi*t_s), ft[s] the scalar
  * forcing of step s, fcol[c] a per-column offset (forcing = ft[s] + fcol[c]; pass NULL for 0).
  * counters[0] += tridiagonal solves, counters[1] += steps whose iteration hit MAX_NEWTON. */
-int ebmo_miz_run(int kind, int nx, int ncol, const double *x, const double *par, double dt,
-                 int nsteps, const double *ct, const double *ft, const double *fcol,
-                 double *Ei, double *Ew, double *h, double *D, double *phi, double *T0,
-                 double *Tw, double *Ti, double *n, double *E, double *T, long long *counters,
+static int miz_run_impl(int kind, int nx, int ncol, const real *x, const real *par, real dt,
+                 int nsteps, const real *ct, const real *ft, const real *fcol,
+                 real *Ei, real *Ew, real *h, real *D, real *phi, real *T0,
+                 real *Tw, real *Ti, real *n, real *E, real *T, long long *counters,
                  int nthreads) {
     Geom g;
     geom_init(&g, kind, nx, x, par[P_D]);
@@ -303,7 +321,7 @@ int ebmo_miz_run(int kind, int nx, int ncol, const double *x, const double *par,
         for (int c = 0; c < ncol; ++c) {
             size_t o = (size_t)c * nx;
             for (int s = 0; s < nsteps; ++s) {
-                double f = fcol ? ft[s] + fcol[c] : ft[s];
+                real f = fcol ? ft[s] + fcol[c] : ft[s];
                 int r = miz_step_col(&g, par, nx, x, dt, ct[s], f, Ei + o, Ew + o, h + o, D + o,
                                      phi + o, T0 + o, Tw + o, Ti + o, n + o, E + o, T + o, &w);
                 solves += r < 0 ? -r : r;
@@ -320,21 +338,21 @@ int ebmo_miz_run(int kind, int nx, int ncol, const double *x, const double *par,
 
 /* Residual of the reference's T0eq (src/miz.jl:33-45) at a given T0, one column — lets tests
  * check a T0 against the reference solver's own acceptance criterion (abstol 1e-8). */
-void ebmo_T0eq(int kind, int nx, const double *x, const double *par, double ct, double f,
-               const double *h, const double *Ew, const double *phi, const double *T0,
-               double *res) {
+static void T0eq_impl(int kind, int nx, const real *x, const real *par, real ct, real f,
+               const real *h, const real *Ew, const real *phi, const real *T0,
+               real *res) {
     Geom g;
     geom_init(&g, kind, nx, x, par[P_D]);
-    const double Tm = par[P_Tm];
-    double *tb = malloc(sizeof(double) * nx);
+    const real Tm = par[P_Tm];
+    real *tb = malloc(sizeof(real) * nx);
     for (int k = 0; k < nx; ++k) {
-        double tw = Tm + Ew[k] / ((1.0 - phi[k]) * par[P_cw]);
+        real tw = Tm + Ew[k] / ((1.0 - phi[k]) * par[P_cw]);
         if (isnan(tw)) tw = 0.0;
         tb[k] = jl_min(T0[k], Tm) * phi[k] + (1.0 - phi[k]) * tw;
     }
     for (int k = 0; k < nx; ++k) {
-        double hp = (h[k] == 0.0) ? par[P_hmin] : h[k];
-        double v = par[P_k] * (Tm - T0[k]) / hp;
+        real hp = (h[k] == 0.0) ? par[P_hmin] : h[k];
+        real v = par[P_k] * (Tm - T0[k]) / hp;
         v = v + par[P_ai] * insolation(par, x[k], ct);
         v = v + ((-par[P_A]) - par[P_B] * (T0[k] - Tm));
         v = diffusion_add(&g, v, tb, k);
@@ -345,22 +363,22 @@ void ebmo_T0eq(int kind, int nx, const double *x, const double *par, double ct, 
 }
 
 /* ---- classic model, src/classic.jl ---- */
-int ebmo_classic_run(int nx, int ncol, const double *x, const double *par, double dt, int nsteps,
-                     const double *ct_i, const double *ct_ip1, const double *ft,
-                     const double *fcol, double *E, double *Tg, double *T, double *h,
+static int classic_run_impl(int nx, int ncol, const real *x, const real *par, real dt, int nsteps,
+                     const real *ct_i, const real *ct_ip1, const real *ft,
+                     const real *fcol, real *E, real *Tg, real *T, real *h,
                      int nthreads) {
     Geom g;
     geom_init(&g, 0, nx, x, 1.0);                       /* get_diffop(nx), unscaled */
-    const double A = par[P_A], cw = par[P_cw], ai = par[P_ai], Lf = par[P_Lf], Fb = par[P_Fb];
-    const double cg_tau = par[P_cg] / par[P_tau];       /* get_statics :18-29 */
-    const double dt_tau = dt / par[P_tau];
-    const double dc = dt_tau * cg_tau;
-    const double dtD = dt * par[P_D];
-    const double one = 1.0 + dt_tau;
-    const double M = par[P_B] + cg_tau;
-    const double kLf = par[P_k] * par[P_Lf];
-    size_t nb = sizeof(double) * (size_t)nx;
-    double *ksub = malloc(nb), *kdiag = malloc(nb), *ksup = malloc(nb), *aw = malloc(nb),
+    const real A = par[P_A], cw = par[P_cw], ai = par[P_ai], Lf = par[P_Lf], Fb = par[P_Fb];
+    const real cg_tau = par[P_cg] / par[P_tau];       /* get_statics :18-29 */
+    const real dt_tau = dt / par[P_tau];
+    const real dc = dt_tau * cg_tau;
+    const real dtD = dt * par[P_D];
+    const real one = 1.0 + dt_tau;
+    const real M = par[P_B] + cg_tau;
+    const real kLf = par[P_k] * par[P_Lf];
+    size_t nb = sizeof(real) * (size_t)nx;
+    real *ksub = malloc(nb), *kdiag = malloc(nb), *ksup = malloc(nb), *aw = malloc(nb),
            *Sb = malloc(nb);
     for (int k = 0; k < nx; ++k) {
         ksub[k] = 0.0 - (dtD * g.c0[k]) / par[P_cg];
@@ -374,27 +392,27 @@ int ebmo_classic_run(int nx, int ncol, const double *x, const double *par, doubl
 #pragma omp parallel
 #endif
     {
-        double *b = malloc(nb), *d = malloc(nb), *cp = malloc(nb), *dp = malloc(nb),
+        real *b = malloc(nb), *d = malloc(nb), *cp = malloc(nb), *dp = malloc(nb),
                *xs = malloc(nb);
 #ifdef _OPENMP
 #pragma omp for schedule(static)
 #endif
         for (int c = 0; c < ncol; ++c) {
-            double *Ec = E + (size_t)c * nx, *Tgc = Tg + (size_t)c * nx;
-            double *Tc = T + (size_t)c * nx, *hc = h + (size_t)c * nx;
+            real *Ec = E + (size_t)c * nx, *Tgc = Tg + (size_t)c * nx;
+            real *Tc = T + (size_t)c * nx, *hc = h + (size_t)c * nx;
             for (int s = 0; s < nsteps; ++s) {
-                double f = fcol ? ft[s] + fcol[c] : ft[s];
+                real f = fcol ? ft[s] + fcol[c] : ft[s];
                 for (int k = 0; k < nx; ++k) {          /* src/classic.jl:47-65 */
-                    double Ek = Ec[k];
-                    double S_i = Sb[k] - (par[P_S1] * ct_i[s]) * x[k];
-                    double S_ip1 = Sb[k] - (par[P_S1] * ct_ip1[s]) * x[k];
-                    double alpha = bool_mul(aw[k], Ek > 0.0) + bool_mul(ai, Ek < 0.0);
-                    double C = alpha * S_i + cg_tau * Tgc[k] - A + f;
-                    double T0 = C / (M - kLf / Ek);
-                    double Tk = bool_mul(Ek / cw, Ek >= 0.0) + bool_mul(bool_mul(T0, Ek < 0.0), T0 < 0.0);
+                    real Ek = Ec[k];
+                    real S_i = Sb[k] - (par[P_S1] * ct_i[s]) * x[k];
+                    real S_ip1 = Sb[k] - (par[P_S1] * ct_ip1[s]) * x[k];
+                    real alpha = bool_mul(aw[k], Ek > 0.0) + bool_mul(ai, Ek < 0.0);
+                    real C = alpha * S_i + cg_tau * Tgc[k] - A + f;
+                    real T0 = C / (M - kLf / Ek);
+                    real Tk = bool_mul(Ek / cw, Ek >= 0.0) + bool_mul(bool_mul(T0, Ek < 0.0), T0 < 0.0);
                     Ek = Ek + dt * (C - M * Tk + Fb);
-                    double den = M - kLf / Ek;
-                    double q = bool_mul(bool_mul(dc / den, T0 < 0.0), Ek < 0.0);
+                    real den = M - kLf / Ek;
+                    real q = bool_mul(bool_mul(dc / den, T0 < 0.0), Ek < 0.0);
                     d[k] = Tgc[k] + dt_tau * (bool_mul(Ek / cw, Ek >= 0.0) +
                                bool_mul(bool_mul((ai * S_ip1 - A + f) / den, T0 < 0.0), Ek < 0.0));
                     b[k] = kdiag[k] - q;
@@ -415,18 +433,95 @@ int ebmo_classic_run(int nx, int ncol, const double *x, const double *par, doubl
 
 /* Geometry export so tests can compare the C and NumPy restatements coefficient by
  * coefficient.  out: 8 arrays of nx (c0..c4, lo, di, up). */
-void ebmo_geometry(int kind, int nx, const double *x, double D, double *out) {
+static void geometry_impl(int kind, int nx, const real *x, real D, real *out) {
     Geom g;
     geom_init(&g, kind, nx, x, D);
-    double *src[8] = {g.c0, g.c1, g.c2, g.c3, g.c4, g.lo, g.di, g.up};
-    for (int i = 0; i < 8; ++i) memcpy(out + (size_t)i * nx, src[i], sizeof(double) * nx);
+    real *src[8] = {g.c0, g.c1, g.c2, g.c3, g.c4, g.lo, g.di, g.up};
+    for (int i = 0; i < 8; ++i) memcpy(out + (size_t)i * nx, src[i], sizeof(real) * nx);
     geom_free(&g);
 }
 
-int ebmo_max_threads(void) {
+int EBMO(max_threads)(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
 #else
     return 1;
 #endif
+}
+
+/* ---- exported entry points: fp64 arrays in and out ----------------------------------------------
+ * double build: the implementations above, called directly (no copies).  Extended build: inputs are
+ * widened exactly, the whole run is carried in `real`, results are rounded to fp64 once at the end. */
+#ifdef EBMO_LONG
+static real *widen(const double *v, size_t n) {
+    if (!v) return NULL;
+    real *o = malloc(sizeof(real) * (n ? n : 1));
+    for (size_t i = 0; i < n; ++i) o[i] = v[i];
+    return o;
+}
+static void narrow(double *dst, const real *src, size_t n) {
+    for (size_t i = 0; i < n; ++i) dst[i] = (double)src[i];
+}
+#define WIDEN(name, n) real *name##_r = widen(name, n)
+#define RARG(name) name##_r
+#define NARROW_FREE(name, n) do { if (name) narrow(name, name##_r, n); free(name##_r); } while (0)
+#define JUST_FREE(name) free(name##_r)
+#else
+#define WIDEN(name, n) (void)0
+#define RARG(name) name
+#define NARROW_FREE(name, n) (void)0
+#define JUST_FREE(name) (void)0
+#endif
+
+void EBMO(thomas)(int n, const double *a, const double *b, const double *c, const double *d, double *xs) {
+    WIDEN(a, n); WIDEN(b, n); WIDEN(c, n); WIDEN(d, n); WIDEN(xs, n);
+    thomas_export(n, RARG(a), RARG(b), RARG(c), RARG(d), RARG(xs));
+    JUST_FREE(a); JUST_FREE(b); JUST_FREE(c); JUST_FREE(d); NARROW_FREE(xs, n);
+}
+
+int EBMO(miz_run)(int kind, int nx, int ncol, const double *x, const double *par, double dt,
+                  int nsteps, const double *ct, const double *ft, const double *fcol,
+                  double *Ei, double *Ew, double *h, double *D, double *phi, double *T0,
+                  double *Tw, double *Ti, double *n, double *E, double *T, long long *counters,
+                  int nthreads) {
+    const size_t N = (size_t)ncol * nx;
+    (void)N;
+    WIDEN(x, nx); WIDEN(par, P_COUNT); WIDEN(ct, nsteps); WIDEN(ft, nsteps); WIDEN(fcol, ncol);
+    WIDEN(Ei, N); WIDEN(Ew, N); WIDEN(h, N); WIDEN(D, N); WIDEN(phi, N); WIDEN(T0, N);
+    WIDEN(Tw, N); WIDEN(Ti, N); WIDEN(n, N); WIDEN(E, N); WIDEN(T, N);
+    int rc = miz_run_impl(kind, nx, ncol, RARG(x), RARG(par), dt, nsteps, RARG(ct), RARG(ft), RARG(fcol),
+                          RARG(Ei), RARG(Ew), RARG(h), RARG(D), RARG(phi), RARG(T0), RARG(Tw), RARG(Ti),
+                          RARG(n), RARG(E), RARG(T), counters, nthreads);
+    JUST_FREE(x); JUST_FREE(par); JUST_FREE(ct); JUST_FREE(ft); JUST_FREE(fcol);
+    NARROW_FREE(Ei, N); NARROW_FREE(Ew, N); NARROW_FREE(h, N); NARROW_FREE(D, N); NARROW_FREE(phi, N);
+    NARROW_FREE(T0, N); NARROW_FREE(Tw, N); NARROW_FREE(Ti, N); NARROW_FREE(n, N); NARROW_FREE(E, N);
+    NARROW_FREE(T, N);
+    return rc;
+}
+
+void EBMO(T0eq)(int kind, int nx, const double *x, const double *par, double ct, double f,
+                const double *h, const double *Ew, const double *phi, const double *T0, double *res) {
+    WIDEN(x, nx); WIDEN(par, P_COUNT); WIDEN(h, nx); WIDEN(Ew, nx); WIDEN(phi, nx); WIDEN(T0, nx); WIDEN(res, nx);
+    T0eq_impl(kind, nx, RARG(x), RARG(par), ct, f, RARG(h), RARG(Ew), RARG(phi), RARG(T0), RARG(res));
+    JUST_FREE(x); JUST_FREE(par); JUST_FREE(h); JUST_FREE(Ew); JUST_FREE(phi); JUST_FREE(T0); NARROW_FREE(res, nx);
+}
+
+int EBMO(classic_run)(int nx, int ncol, const double *x, const double *par, double dt, int nsteps,
+                      const double *ct_i, const double *ct_ip1, const double *ft, const double *fcol,
+                      double *E, double *Tg, double *T, double *h, int nthreads) {
+    const size_t N = (size_t)ncol * nx;
+    (void)N;
+    WIDEN(x, nx); WIDEN(par, P_COUNT); WIDEN(ct_i, nsteps); WIDEN(ct_ip1, nsteps); WIDEN(ft, nsteps); WIDEN(fcol, ncol);
+    WIDEN(E, N); WIDEN(Tg, N); WIDEN(T, N); WIDEN(h, N);
+    int rc = classic_run_impl(nx, ncol, RARG(x), RARG(par), dt, nsteps, RARG(ct_i), RARG(ct_ip1), RARG(ft),
+                              RARG(fcol), RARG(E), RARG(Tg), RARG(T), RARG(h), nthreads);
+    JUST_FREE(x); JUST_FREE(par); JUST_FREE(ct_i); JUST_FREE(ct_ip1); JUST_FREE(ft); JUST_FREE(fcol);
+    NARROW_FREE(E, N); NARROW_FREE(Tg, N); NARROW_FREE(T, N); NARROW_FREE(h, N);
+    return rc;
+}
+
+void EBMO(geometry)(int kind, int nx, const double *x, double D, double *out) {
+    WIDEN(x, nx); WIDEN(out, (size_t)8 * nx);
+    geometry_impl(kind, nx, RARG(x), D, RARG(out));
+    JUST_FREE(x); NARROW_FREE(out, (size_t)8 * nx);
 }

@@ -16,6 +16,37 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# The 2-process Engine test needs a fresh pair of ranks started BEFORE this process has touched the
+# GPU (a process that has initialised HIP must not spawn the launcher: on this pool an exec from such
+# a process is refused).  So the launcher is started here, at session start, whenever GPU tests are
+# selected and a device is present; tests/test_gpu_configs.py waits for it and checks its output.
+TWO_RANK = {"proc": None, "out": None, "log": None}
+
+
+def pytest_sessionstart(session):
+    import subprocess
+    import tempfile
+    markexpr = session.config.getoption("-m") or ""
+    if "gpu" not in markexpr or "not gpu" in markexpr:
+        return
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:          # counting devices does not initialise the GPU
+            return
+    except Exception:
+        return
+    tmp = tempfile.mkdtemp(prefix="ebm_two_rank_")
+    TWO_RANK["out"] = os.path.join(tmp, "gathered.npz")
+    TWO_RANK["log"] = os.path.join(tmp, "two_rank.log")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with open(TWO_RANK["log"], "w") as log:
+        TWO_RANK["proc"] = subprocess.Popen(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+             "--master-addr", "127.0.0.1", "--master-port", "29541",
+             os.path.join(ROOT, "tests", "two_rank_worker.py"), TWO_RANK["out"]],
+            env=env, stdout=log, stderr=subprocess.STDOUT)
+
+
 @pytest.fixture(scope="session")
 def pkg():
     return graft.load_package()

@@ -1,0 +1,138 @@
+"""GPU tests (-m gpu): every BASELINE.json configuration at its stated size, driven through the
+product's own host layer (Engine / EnsembleRun / shard_columns / gather_columns) and checked against
+the oracle on sampled columns plus size-independent properties — and the multi-process path with two
+real processes driving the HIP library.
+
+  configs[2]  2-D 1024 x 512 classic model                           test_config3_classic_1024x512
+  configs[4]  256-member ensemble of the 1024 x 512 MIZ model,
+              32 members per GPU: this GPU's share                    test_config5_per_gpu_share
+  SURVEY 8(e) two ranks, each its block of columns, gather to rank 0  test_two_process_sharded_engine
+(configs[0], [1] and [3] are in test_gpu_parity.py: golden trajectory, 1440-band sizes case,
+test_full_size_4096x2048_properties.)
+"""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import conftest
+from conftest import ROOT, scaled_err
+
+pytestmark = pytest.mark.gpu
+
+PROG = ("Ei", "Ew", "h", "D", "phi")
+DIAG = ("Tw", "Ti", "n", "E", "T")
+
+
+def test_config3_classic_1024x512(pkg, coracle):
+    """1024 latitudes x 512 meridians, identity grid, nt = 2000, WE15-style warm
+    start, f[lon] = 0.5 sin(2 pi lon/512).  120 steps on the GPU; 24 sampled meridians against the
+    oracle; meridians with equal forcing bitwise equal; E, T, h of the FIRST step bit-exact."""
+    nlat, nlon, nt, nsteps = 1024, 512, 2000, 120
+    st = pkg.SpaceTime("identity", nlat, nt, 1)
+    par = pkg.default_parameters("Classic")
+    Ts = 30.0 - 45.0 * st.x ** 2
+    init = dict(E=np.where(Ts >= 0, par["cw"] * Ts, par["Lf"] * Ts / 7.5), Tg=Ts)
+    fcol = 0.5 * np.sin(2.0 * np.pi * np.arange(nlon) / nlon)
+    fcol[300:] = fcol[100:312]                                  # lon >= 300 repeats lon - 200
+    run = pkg.EnsembleRun("Classic", st, par, init, fcol=fcol, device=0)
+    run.run(1)
+    first = run.state(("E", "Tg", "T", "h"))
+    run.run(nsteps - 1)
+    got = run.state(("E", "Tg", "T", "h"))
+    run.close()
+    sample = np.arange(3, nlon, 22)
+    ct = np.array([pkg.cos2pit(float(t)) for t in st.t])
+    idx = np.arange(nsteps)
+
+    def oracle(n):
+        state = dict(E=np.tile(init["E"], (len(sample), 1)), Tg=np.tile(init["Tg"], (len(sample), 1)))
+        out = coracle.classic_run(st.x, dict(par), st.dt, ct[idx[:n]], ct[(idx[:n] + 1) % nt], np.zeros(n),
+                                  fcol[sample], state)
+        return dict(state, **out)
+
+    ref1 = oracle(1)
+    for k in ("E", "T", "h"):                                    # pointwise physics: bit-exact
+        assert np.array_equal(first[k][sample], ref1[k], equal_nan=True), k
+    ref = oracle(nsteps)
+    for k in ("E", "Tg", "T", "h"):
+        e = scaled_err(got[k][sample], ref[k])
+        assert e <= 1e-9, f"{k}: {e:.3e}"                        # measured 2e-12 (profiles/r02_error_budget.txt)
+    for k in got:
+        assert np.array_equal(got[k][300:], got[k][100:312], equal_nan=True), k
+    assert np.any(got["h"] > 0) and np.any(got["h"] == 0)       # ice cap and open water both present
+
+
+def test_config5_per_gpu_share(pkg, coracle):
+    """BASELINE configs[4] / SURVEY 8(d) cfg5, the share of one GPU: 32 members x 512 meridians of the
+    1024-latitude MIZ model (16,384 columns, 768 MiB of prognostic state), member m forced by the
+    constant f_m = -2 + 4 m/255 W/m2, zero initial state as in the reference test, nt = 65,536.
+    (1) one sampled meridian of 8 members against the oracle; (2) the 512 meridians of a member are
+    bitwise equal; (3) per-member hemispheric means reduced on the device == the host loop of
+    src/utilities.jl:397-403; (4) shard_columns tiles the 256-member ensemble over 8 ranks."""
+    nlat, nlon, nmember_gpu, nt, nsteps = 1024, 512, 32, 65536, 24
+    rank, world = 3, 8                                          # any rank's share is the same workload
+    st = pkg.SpaceTime("sin", nlat, nt, 1)
+    par = pkg.default_parameters("MIZ")
+    total_cols = 256 * nlon
+    sl = pkg.shard_columns(total_cols, world, rank)
+    assert sl.stop - sl.start == nmember_gpu * nlon
+    assert [pkg.shard_columns(total_cols, world, r).start for r in range(world)] == [r * 16384 for r in range(world)]
+    member = np.arange(sl.start, sl.stop) // nlon               # global member index of every column
+    assert member.min() == rank * 32 and member.max() == rank * 32 + 31
+    fcol = -2.0 + 4.0 * member / 255.0
+    init = {k: np.zeros(nlat) for k in PROG}
+    run = pkg.EnsembleRun("MIZ", st, par, init, fcol=fcol, device=0)
+    run.run(nsteps)
+    got = run.state(PROG + DIAG)
+    hm_T, hm_phi = run.engine.hemispheric_mean("T"), run.engine.hemispheric_mean("phi")
+    cnt = run.engine.counters()
+    run.close()
+    assert cnt["cap_hits"] == 0 and cnt["steps"] == nsteps
+    # (2) replicated forcing
+    for k in PROG + DIAG:
+        a = got[k].reshape(nmember_gpu, nlon, nlat)
+        assert np.array_equal(a[:, 0], a[:, 255], equal_nan=True) and np.array_equal(a[:, 0], a[:, 511], equal_nan=True), k
+    # (1) sampled members against the oracle
+    sample = np.arange(0, nmember_gpu, 4) * nlon + 7
+    state = {k: np.zeros((len(sample), nlat)) for k in PROG + ("T0",)}
+    ct = np.array([pkg.cos2pit(float(t)) for t in st.t[:nsteps]])
+    diag, ocnt = coracle.miz_run(1, st.x, dict(par), st.dt, ct, np.zeros(nsteps), fcol[sample], state)
+    ref = dict(state, **diag)
+    for k in PROG + DIAG:
+        e = scaled_err(got[k][sample], ref[k])
+        assert e <= 1e-9, f"{k}: {e:.3e}"                        # measured 3e-11 (profiles/r02_error_budget.txt)
+    # (3) diagnostics reduced on the device
+    assert np.array_equal(hm_T, pkg.hemispheric_mean(got["T"], st.x), equal_nan=True)
+    assert np.array_equal(hm_phi, pkg.hemispheric_mean(got["phi"], st.x), equal_nan=True)
+    by_member = hm_T.reshape(nmember_gpu, nlon)[:, 0]
+    assert np.all(np.diff(by_member) > 0)                       # warmer forcing, warmer hemisphere
+
+
+def test_two_process_sharded_engine(pkg):
+    """Two processes (a fresh ``torch.distributed.run`` pair started by conftest.py before this process
+    touched the GPU), each driving the HIP library on its shard_columns block of a 5-member x 8-meridian
+    ensemble, per-column diagnostics reduced on the device, gathered to rank 0 — against one process
+    integrating all 40 columns: bit for bit."""
+    info = conftest.TWO_RANK
+    if info["proc"] is None:
+        pytest.skip("the two-rank launcher was not started (no GPU at session start)")
+    rc = info["proc"].wait(timeout=900)
+    log = open(info["log"]).read()
+    keep = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(keep, exist_ok=True)
+    shutil.copy(info["log"], os.path.join(keep, "two_rank_rehearsal.log"))
+    assert rc == 0, log[-3000:]
+    assert "rank 0/2" in log and "rank 1/2" in log and "rank 0 gathered 40 columns" in log
+    got = np.load(info["out"])
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("two_rank_worker", os.path.join(ROOT, "tests", "two_rank_worker.py"))
+    worker = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(worker)
+    ncol = worker.NLON * worker.NMEMBER
+    T, hmT, hmphi = worker.run_block(pkg, np.arange(ncol))
+    assert np.array_equal(got["T"], T.cpu().numpy(), equal_nan=True)
+    assert np.array_equal(got["hmT"], hmT.cpu().numpy(), equal_nan=True)
+    assert np.array_equal(got["hmphi"], hmphi.cpu().numpy(), equal_nan=True)
+    assert got["T"].shape == (ncol, worker.NLAT) and len(np.unique(got["hmT"])) == worker.NMEMBER

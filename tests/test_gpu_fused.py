@@ -1,0 +1,278 @@
+"""GPU tests (-m gpu) of the round-2 launch paths, all through the C ABI:
+
+* fused-K stepping (ebm_run_fused): K steps per launch, state in registers between steps —
+  bit-identical to one launch per step (reference loop: src/infrastructure.jl:630-634);
+* savesol! fused into the step kernel (ebm_integrate): one launch per step, the annual-mean sums
+  and raw snapshots taken from the step's registers — the mean must equal, bit for bit, the
+  sequential per-cell sum of the raw snapshots divided by nt (src/infrastructure.jl:549-591,
+  src/utilities.jl:390-395);
+* the device-pointer entry points.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, scaled_err
+
+pytestmark = pytest.mark.gpu
+
+PROG = ("Ei", "Ew", "h", "D", "phi")
+DIAG = ("Tw", "Ti", "n", "E", "T")
+ALL = PROG + ("T0",) + DIAG
+MIZ_VARS = ("E", "T", "h", "Ei", "Ew", "Ti", "Tw", "D", "phi", "n")
+
+
+def make_engine(pkg, model, st, par, ncol=1):
+    return pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval),
+                      st.dt, ncol, device=0)
+
+
+def classic_init(pkg, st, par, ncol):
+    Ts = 30.0 - 45.0 * st.x ** 2
+    E0 = np.where(Ts >= 0, par["cw"] * Ts, par["Lf"] * Ts / 7.5)
+    return dict(E=np.tile(E0, (ncol, 1)), Tg=np.tile(Ts, (ncol, 1)))
+
+
+# ---- fused-K stepping ---------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,nlat,ncol,nt,K", [
+    ("sin", 180, 1, 2000, 64),            # BASELINE configs[0] shape: one wave
+    ("sin", 180, 3, 2000, 7),
+    ("identity", 180, 2, 2000, 50),
+    ("sin", 63, 2, 2000, 16),             # ragged single wave
+    ("sin", 1440, 1, 131072, 32),         # BASELINE configs[1]: six waves
+    ("identity", 1000, 2, 60000, 5),
+    ("sin", 2048, 3, 262144, 9),          # the largest meridian with a fused kernel (512 threads)
+    ("sin", 2045, 2, 262144, 4),
+])
+def test_fused_run_equals_single_steps(pkg, kind, nlat, ncol, nt, K):
+    """K steps per launch against one launch per step: same operations on the same values, so every
+    field — prognostics, the T0 of the last step, the diagnostics, NaN sentinels — is bitwise equal.
+    Varying per-step forcing, per-column offsets, a run length that is not a multiple of K, a start
+    late in the year (time index wraps), state handed over between two fused calls."""
+    st = pkg.SpaceTime(kind, nlat, nt, 1)
+    par = pkg.default_parameters("MIZ")
+    nsteps = 3 * K + 5
+    first = nt - 2 * K                                         # wraps around the year end
+    f_steps = 0.3 * np.sin(np.arange(nsteps) / 5.0)
+    fcol = np.linspace(-1.5, 1.5, ncol) if ncol > 1 else np.array([0.4])
+    out, cnt = {}, {}
+    for mode in ("single", "fused"):
+        with make_engine(pkg, "MIZ", st, par, ncol) as eng:
+            eng.set_column_forcing(fcol)
+            eng.set_time_table(st.t)
+            eng.run(0, 40, None, False)                        # freeze-up: ice edge and T0 solve live
+            eng.reset_counters()
+            if mode == "single":
+                eng.run(first, nsteps, f_steps, True)
+            else:
+                half = K + 3
+                eng.run(first, half, f_steps[:half], False, steps_per_launch=K)
+                eng.run(first + half, nsteps - half, f_steps[half:], True, steps_per_launch=K)
+            out[mode] = eng.get_state(ALL)
+            cnt[mode] = eng.counters()
+    for k in ALL:
+        assert np.array_equal(out["single"][k], out["fused"][k], equal_nan=True), k
+    assert np.any(out["single"]["phi"] > 0) and np.any(out["single"]["phi"] == 0)
+    assert cnt["fused"]["steps"] == cnt["single"]["steps"] == nsteps
+    assert cnt["fused"]["solves"] == cnt["single"]["solves"] and cnt["fused"]["cap_hits"] == 0
+    assert cnt["single"]["launches"] == nsteps
+    assert cnt["fused"]["launches"] == -(-(K + 3) // K) + -(-(nsteps - K - 3) // K)
+
+
+def test_fused_run_with_column_schedules(pkg):
+    """Per-column Forcing schedules are evaluated at the model time of every fused step."""
+    st = pkg.SpaceTime("sin", 180, 2000, 3)
+    par = pkg.default_parameters("MIZ")
+    members = [pkg.Forcing(0.5), pkg.Forcing(0.0, 2.0, 0.0, (1, 0), (2.0, -2.0)),
+               pkg.Forcing(-1.0, 1.0, 0.0, (0, 1), (2.0, -1.0))]
+    out = {}
+    for K in (1, 37):
+        with make_engine(pkg, "MIZ", st, par, 3) as eng:
+            eng.set_time_table(st.t)
+            eng.set_column_schedules(members)
+            eng.run(1900, 2300, None, True, steps_per_launch=K)
+            out[K] = eng.get_state(ALL)
+    for k in ALL:
+        assert np.array_equal(out[1][k], out[37][k], equal_nan=True), k
+    assert np.any(out[1]["Ew"][0] != out[1]["Ew"][1])
+
+
+@pytest.mark.parametrize("nlat,ncol,K", [(180, 2, 25), (1024, 3, 8), (333, 1, 100)])
+def test_fused_run_classic(pkg, nlat, ncol, K):
+    """Classic model: E and Tg stay in registers across the K steps of a launch."""
+    st = pkg.SpaceTime("identity", nlat, 2000, 1)
+    par = pkg.default_parameters("Classic")
+    nsteps = 2 * K + 3
+    f_steps = 0.5 * np.cos(np.arange(nsteps) / 3.0)
+    out = {}
+    for mode in (1, K):
+        with make_engine(pkg, "Classic", st, par, ncol) as eng:
+            eng.set_state(classic_init(pkg, st, par, ncol))
+            eng.set_column_forcing(np.linspace(-1.0, 1.0, ncol))
+            eng.set_time_table(st.t)
+            eng.run(1995, nsteps, f_steps, True, steps_per_launch=mode)
+            out[mode] = eng.get_state(("E", "Tg", "T", "h"))
+            assert eng.counters()["launches"] == (nsteps if mode == 1 else 3)
+    for k in out[1]:
+        assert np.array_equal(out[1][k], out[K][k], equal_nan=True), k
+
+
+def test_fused_run_long_meridians_fall_back_to_single_launches(pkg):
+    """Meridians of more than 2048 cells have no fused kernel (their state does not fit the register
+    file): ebm_run_fused then launches every step, as documented, with identical results."""
+    st = pkg.SpaceTime("sin", 4096, 1048576, 1)
+    par = pkg.default_parameters("MIZ")
+    out = {}
+    for K in (1, 16):
+        with make_engine(pkg, "MIZ", st, par, 2) as eng:
+            eng.set_column_forcing(np.array([-0.5, 0.5]))
+            eng.set_time_table(st.t)
+            eng.run(0, 40, None, True, steps_per_launch=K)
+            out[K] = eng.get_state(ALL)
+            assert eng.counters()["launches"] == 40
+    for k in ALL:
+        assert np.array_equal(out[1][k], out[16][k], equal_nan=True), k
+
+
+def test_fused_run_matches_oracle(pkg, coracle):
+    """The fused path against the oracle directly (not only against the per-step path)."""
+    nlat, nt, nsteps = 1440, 131072, 60
+    st = pkg.SpaceTime("sin", nlat, nt, 1)
+    par = pkg.default_parameters("MIZ")
+    ct = np.array([pkg.cos2pit(float(t)) for t in st.t[:nsteps]])
+    state = {k: np.zeros((1, nlat)) for k in PROG + ("T0",)}
+    diag, ocnt = coracle.miz_run(1, st.x, dict(par), st.dt, ct, np.zeros(nsteps), None, state)
+    with make_engine(pkg, "MIZ", st, par, 1) as eng:
+        eng.set_time_table(st.t)
+        eng.run(0, nsteps, None, True, steps_per_launch=20)
+        got = eng.get_state(ALL)
+        cnt = eng.counters()
+    ref = dict(state, **diag)
+    for k in ALL:
+        assert scaled_err(got[k], ref[k]) <= 1e-10 * (nlat / 256.0) ** 2, k
+    assert cnt["solves"] == ocnt[0] and cnt["launches"] == 3
+
+
+# ---- savesol! fused into the step kernel ----------------------------------------------------------
+def sequential_mean(raw, nt):
+    """crossmean as the device accumulates it: per cell, sum over the year's steps in step order
+    (one IEEE addition per step, starting from +0.0), then one division by nt."""
+    acc = np.zeros(raw.shape[:1] + raw.shape[2:])
+    for ti in range(raw.shape[1]):
+        acc = acc + raw[:, ti]
+    return acc / float(nt)
+
+
+@pytest.mark.parametrize("model,kind,nlat,ncol,nt,dur", [
+    ("MIZ", "sin", 180, 2, 400, 2),
+    ("MIZ", "identity", 255, 3, 600, 1),          # ragged: padding cells of sums and snapshots
+    ("MIZ", "sin", 1024, 2, 70000, 1),            # 256 threads; only the first 300 steps of the year are run
+    ("Classic", "identity", 180, 2, 400, 2),
+    ("Classic", "identity", 333, 1, 500, 1),
+])
+def test_integrate_saves_from_registers(pkg, model, kind, nlat, ncol, nt, dur):
+    """ebm_integrate takes the annual-mean sums and the raw snapshots from the step kernel's
+    registers (one launch per step).  (1) avg == sequential sum of the raw snapshots / nt, bit for
+    bit; (2) the last raw snapshot is the final state; (3) winter / summer snapshots are the raw
+    snapshots of those steps; (4) launches == steps + nothing else per step."""
+    short = nt > 5000
+    if short:
+        nt_run = 300                                           # a 300-step "year" of the same dt
+        st = pkg.SpaceTime(kind, nlat, nt, 1)
+        st_run = pkg.SpaceTime(kind, nlat, nt_run, 1)
+        st_run.dt = st.dt
+    else:
+        st_run = pkg.SpaceTime(kind, nlat, nt, dur)
+        nt_run = nt
+    par = pkg.default_parameters(model)
+    names = MIZ_VARS if model == "MIZ" else ("E", "T", "h", "Tg")
+    total = nt_run * dur
+    f_steps = 0.4 * np.sin(np.arange(total) / 11.0)
+    with make_engine(pkg, model, st_run, par, ncol) as eng:
+        if model == "Classic":
+            eng.set_state(classic_init(pkg, st_run, par, ncol))
+        eng.set_column_forcing(np.linspace(-1.0, 2.0, ncol))
+        eng.set_time_table(st_run.t)
+        eng.reset_counters()
+        out = eng.integrate(nt_run, dur, f_steps, False, st_run.winter.inx, st_run.summer.inx, names)
+        final = eng.get_state(names)
+        cnt = eng.counters()
+    raw = out["raw"]
+    assert raw.shape == (len(names), total, ncol, nlat)
+    for y in range(dur):
+        ref = sequential_mean(raw[:, y * nt_run:(y + 1) * nt_run], nt_run)
+        assert np.array_equal(out["avg"][:, y], ref, equal_nan=True), f"year {y}"
+        assert np.array_equal(out["winter"][:, y], raw[:, y * nt_run + st_run.winter.inx - 1], equal_nan=True)
+        assert np.array_equal(out["summer"][:, y], raw[:, y * nt_run + st_run.summer.inx - 1], equal_nan=True)
+    for vi, v in enumerate(names):
+        assert np.array_equal(raw[vi, -1], final[v], equal_nan=True), v
+    assert cnt["launches"] == cnt["steps"] == total
+    if model == "MIZ":
+        assert np.isnan(out["avg"][names.index("Ti")]).any()   # NaN sentinels propagate into the mean
+
+
+def test_integrate_avg_only_and_lastonly(pkg):
+    """avg without seasonal snapshots or raw output (Engine.integrate(want_seasonal=False)): the sums
+    run on every step, nothing else is stored; lastonly keeps the last year's raw snapshots only.
+    All three ways of asking give the same means, bit for bit."""
+    st = pkg.SpaceTime("sin", 180, 500, 3)
+    par = pkg.default_parameters("MIZ")
+    res = {}
+    for mode in ("avg_only", "lastonly", "full"):
+        with make_engine(pkg, "MIZ", st, par, 2) as eng:
+            eng.set_column_forcing(np.array([0.0, 1.0]))
+            eng.set_time_table(st.t)
+            res[mode] = eng.integrate(st.nt, st.dur, None, mode != "full", st.winter.inx, st.summer.inx, MIZ_VARS,
+                                      want_raw=(mode != "avg_only"), want_seasonal=(mode != "avg_only"))
+    assert res["avg_only"]["raw"] is None and res["avg_only"]["winter"] is None
+    assert res["avg_only"]["avg"] is not None and not np.all(np.isnan(res["avg_only"]["avg"]))
+    assert res["lastonly"]["raw"].shape[1] == st.nt and res["full"]["raw"].shape[1] == st.nt * st.dur
+    for mode in ("avg_only", "lastonly"):
+        assert np.array_equal(res[mode]["avg"], res["full"]["avg"], equal_nan=True), mode
+    assert np.array_equal(res["lastonly"]["raw"], res["full"]["raw"][:, -st.nt:], equal_nan=True)
+
+
+def test_integrate_rejects_the_hidden_warm_start(pkg):
+    st = pkg.SpaceTime("sin", 64, 100, 1)
+    with make_engine(pkg, "MIZ", st, pkg.default_parameters("MIZ")) as eng:
+        eng.set_time_table(st.t)
+        with pytest.raises(pkg.EBMError, match="not a solution variable"):
+            eng.integrate(st.nt, 1, None, True, st.winter.inx, st.summer.inx, ("E", "T0"))
+        with pytest.raises(pkg.EBMError, match="listed twice"):
+            eng.integrate(st.nt, 1, None, True, st.winter.inx, st.summer.inx, ("E", "E"))
+
+
+# ---- device-pointer entry points ----------------------------------------------------------------
+def test_device_pointer_entry_points(pkg):
+    """ebm_field_device_ptr (zero-copy view), ebm_get_field_device (packed device copy) and
+    ebm_hemispheric_mean_device against the host-copy entry points, through torch tensors on the
+    handle's device (no host staging)."""
+    import torch
+    nlat, ncol = 255, 5                                       # pitch 256 > nlat: the view is strided
+    st = pkg.SpaceTime("sin", nlat, 8000, 1)
+    par = pkg.default_parameters("MIZ")
+    run = pkg.EnsembleRun("MIZ", st, par, {k: np.zeros(nlat) for k in PROG},
+                          fcol=np.linspace(-2.0, 2.0, ncol), device=0)
+    run.run(30)
+    eng = run.engine
+    host = eng.get_field("T")
+    ptr, pitch = eng.field_device_ptr("T")
+    assert ptr and pitch == 256
+    # copy the strided device view [ncol][pitch] out through HIP and compare
+    hip = C.CDLL("libamdhip64.so")
+    buf = np.empty((ncol, pitch))
+    assert hip.hipMemcpy(buf.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(buf.nbytes), 2) == 0
+    assert np.array_equal(buf[:, :nlat], host, equal_nan=True) and np.all(buf[:, nlat:] == 0.0)
+    packed = run.field_tensor("T")
+    assert packed.is_cuda and packed.shape == (ncol, nlat)
+    assert np.array_equal(packed.cpu().numpy(), host, equal_nan=True)
+    for name in ("T", "phi", "Ti"):
+        dev = run.hemispheric_mean_tensor(name)
+        assert dev.is_cuda
+        assert np.array_equal(dev.cpu().numpy(), eng.hemispheric_mean(name), equal_nan=True), name
+    with pytest.raises(pkg.EBMError, match="not part of this model"):
+        eng.field_device_ptr("Tg")
+    # single-process gather is the identity, tensor or array
+    assert np.array_equal(pkg.gather_columns(run.hemispheric_mean_tensor("T"), ncol), eng.hemispheric_mean("T"))
+    run.close()

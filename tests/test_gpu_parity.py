@@ -259,9 +259,8 @@ def test_t0_solve_accuracy_extended_precision(pkg, oracle, coracle, kind, nlat, 
     ("sin", 1000, 5, 60000, 20, 20),      # 256 threads, ragged
     ("sin", 1440, 2, 131072, 50, 20),     # BASELINE configs[1]: 1-D MIZ, 1440 bands
     ("identity", 1024, 8, 262144, 50, 20),  # nt: 2x the explicit stability limit cw dx^2/(2D)
-    ("sin", 4096, 6, 1048576, 50, 10),    # BASELINE configs[3] meridian length, 1024 threads
-    ("sin", 4100, 2, 1048576, 20, 5),     # > 4096: 8 cells per thread
-    ("sin", 8192, 1, 4194304, 10, 3),     # maximum supported meridian length
+    ("sin", 4096, 6, 1048576, 50, 10),    # BASELINE configs[3] meridian length, 1024 threads: the maximum
+    ("sin", 4093, 2, 1048576, 20, 5),     # ragged at the maximum workgroup size
 ])
 def test_miz_sizes_vs_oracle(pkg, coracle, kind, nlat, ncol, nt, spin, nsteps):
     """Spin up with the oracle (ice edge, open water and T0 solve all live), hand the state to
@@ -339,34 +338,12 @@ def test_l2_prefetch_does_not_change_results(pkg, monkeypatch, nlat, ncol, nt):
     assert np.any(out["0"]["Ew"] != 0.0)
 
 
-def test_alternative_geometry_512x8(pkg, coracle, monkeypatch):
-    """EBM_CELLS_PER_THREAD=8 selects 512 threads x 8 cells for 2048 < nlat <= 4096 (a tuning knob:
-    slower on MI355X, kept as a tested alternative).  Same results as the default geometry."""
-    nlat, ncol, nt, spin, nsteps = 4096, 3, 1048576, 30, 5
-    st = pkg.SpaceTime("sin", nlat, nt, 1)
-    par = pkg.default_parameters("MIZ")
-    fcol = np.array([-1.0, 0.0, 1.5])
-    state = {k: np.zeros((ncol, nlat)) for k in PROG + ("T0",)}
-    ct = ctab(pkg, st)
-    coracle.miz_run(1, st.x, dict(par), st.dt, ct[:spin], np.zeros(spin), fcol, state)
-    monkeypatch.setenv("EBM_CELLS_PER_THREAD", "8")
-    with make_engine(pkg, "MIZ", st, par, ncol) as eng:
-        assert eng.launch_info()["cells_per_thread"] == 8 and eng.launch_info()["threads"] == 512
-        eng.set_state(state)
-        eng.set_column_forcing(fcol)
-        eng.set_time_table(st.t)
-        eng.run(spin, nsteps)
-        got = eng.get_state(ALL)
-    diag, _ = coracle.miz_run(1, st.x, dict(par), st.dt, ct[spin:spin + nsteps], np.zeros(nsteps), fcol, state)
-    ref = dict(state)
-    ref.update(diag)
-    check_all(got, ref, size_tol(TOL_SHORT, nlat), what="512x8 geometry")
-
-
 def test_unsupported_and_bad_arguments(pkg):
-    st = pkg.SpaceTime("sin", 8200, 100, 1)
+    st = pkg.SpaceTime("sin", 4097, 100, 1)                 # one workgroup owns a meridian: <= 4096 cells
     with pytest.raises(pkg.EBMError, match="not supported"):
         make_engine(pkg, "MIZ", st, pkg.default_parameters("MIZ"))
+    with pytest.raises(pkg.EBMError, match="not supported"):
+        make_engine(pkg, "Classic", st, pkg.default_parameters("Classic"))
     st = pkg.SpaceTime("sin", 64, 100, 1)
     with make_engine(pkg, "MIZ", st, pkg.default_parameters("MIZ")) as eng:
         with pytest.raises(pkg.EBMError, match="not part of this model"):
