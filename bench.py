@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the median is reported")
     ap.add_argument("--spinup", type=int, default=2000)
+    ap.add_argument("--preroll", type=float, default=PREROLL_S,
+                    help="seconds of untimed steps right before the warm-up (0 under a counter-collecting profiler)")
     ap.add_argument("--workload", default="miz_4096x2048", choices=sorted(WORKLOADS))
     ap.add_argument("--steps-per-launch", type=int, default=1,
                     help="K > 1: fused-K stepping (ebm_run_fused), reported as its own metric")
@@ -189,7 +191,7 @@ def main():
     advance(probe)
     eng.sync()
     per_step = (time.perf_counter() - t0) / probe
-    preroll = 0 if integrate else int(min(200000, max(0, PREROLL_S / max(per_step, 1e-7))))
+    preroll = 0 if integrate else int(min(200000, max(0, args.preroll / max(per_step, 1e-7))))
     if preroll:
         advance(preroll)
     advance(args.warmup) if args.warmup else None

@@ -9,7 +9,12 @@
  *       src/infrastructure.jl:615-636 (+ savesol! :549-591, annual_mean :536-544)
  *
  * The reference is pure Julia and has no FFI of its own; the entry points below are what a
- * Julia `ccall` shim binds (julia/EBMHip.jl).  Plain C: opaque handle,
+ * Julia `ccall` shim binds (julia/EBMHip.jl).  The shim's two supported calls keep
+ * the reference's signatures and model symbols, as functions of the shim module:
+ *     EBMHip.integrate(:MIZ | :Classic, st, forcing, par, init; lastonly, verbose)   -> ebm_integrate
+ *     EBMHip.step!(Val(:MIZ | :Classic), t, f, vars, st, par; verbose)               -> ebm_step
+ * (no new model tag: the reference decides on the symbol's value what a run stores and which
+ * parameters it gets, src/infrastructure.jl:621-624, :473-474).  Plain C: opaque handle,
  * `double*`/`int` only, no C++/torch types.  All arrays are fp64, latitude contiguous:
  * a field is `[ncol][nlat]` in C order == Julia `Array{Float64,2}(nlat, ncol)`; a column is
  * one independent meridian (a longitude of a 2-D grid and/or an ensemble member).

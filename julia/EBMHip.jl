@@ -6,14 +6,29 @@
 # mirror (energybalancemodel.jl_amd/infrastructure.py) makes the same calls through ctypes and is
 # what the tests exercise.
 #
+# THE supported calls (the same two forms are documented in INTEGRATION.md and include/ebm_hip.h):
+#
 #   using EnergyBalanceModel, EBMHip
-#   sols = integrate(:MIZ_HIP, st, forcing, par, init)        # same signature, new model tag
-#   step!(Val(:MIZ_HIP), t, f, vars, st, par)
+#   sols = EBMHip.integrate(:MIZ, st, forcing, par, init; lastonly=true, verbose=false)
+#   EBMHip.step!(Val(:MIZ), t, f, vars, st, par)
+#
+# i.e. the reference's own signatures (src/infrastructure.jl:615-618, src/miz.jl:150-154,
+# src/classic.jl:37-41) and the reference's own model symbols, as functions of THIS module.
+# `EBMHip.integrate` keeps the state on the device for the whole run and fills a `Solutions` exactly
+# as the reference does; `EBMHip.step!` is the per-call form (five fields up, ten down per call).
+#
+# Why there is no `:MIZ_HIP` model tag.  Extending the reference's generic `step!` with a
+# `Val{:MIZ_HIP}` method would make `EnergyBalanceModel.integrate(:MIZ_HIP, ...)` callable, and that
+# call does the wrong thing without failing: the reference's `integrate` only adds the seven MIZ
+# variables to the solution when `model === :MIZ` (src/infrastructure.jl:621-624), so E, T, h alone
+# would be stored, and `default_parameters(:MIZ_HIP)` returns the CLASSIC parameter set
+# (src/infrastructure.jl:473-474).  The reference dispatches on the symbol's VALUE; a new tag cannot
+# be made to mean "MIZ".  Hence: same symbols, functions of this module.
 module EBMHip
 
 using EnergyBalanceModel
 using EnergyBalanceModel.Infrastructure: Vec, Collection, SpaceTime, Forcing, Solutions, default_parval
-import EnergyBalanceModel.Infrastructure: step!, integrate
+import EnergyBalanceModel.Infrastructure
 
 const libebm = get(ENV, "EBM_HIP_LIB", "libebm_hip.so")
 
@@ -36,24 +51,35 @@ gridkind(::SpaceTime) = Cint(1)
 parvec(par::Collection{Float64}) =
     Float64[haskey(getfield(par, :dict), k) ? getproperty(par, k) : getproperty(default_parval, k) for k in PARAM_ORDER]
 
+# One ebm_handle_t.  Every ccall that passes `h.ptr` sits inside `GC.@preserve h`: the pointer alone
+# does not keep `h` alive, and its finalizer calls ebm_destroy.
 mutable struct Handle
     ptr::Ptr{Cvoid}
     function Handle(model::Symbol, st::SpaceTime, par::Collection{Float64}; ncol::Int=1, device::Int=0)
+        haskey(MODEL, model) || throw(MethodError(Infrastructure.step!, (Val(model),)))   # as the reference: no such method
         out = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:ebm_create, libebm), Cint,
                     (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cint),
                     out, MODEL[model], gridkind(st), st.nx, ncol, st.x, parvec(par), st.dt, device), "ebm_create")
         h = new(out[])
-        finalizer(x -> ccall((:ebm_destroy, libebm), Cint, (Ptr{Cvoid},), x.ptr), h)
+        finalizer(destroy!, h)
         return h
     end
 end
+function destroy!(h::Handle)
+    if h.ptr != C_NULL
+        ccall((:ebm_destroy, libebm), Cint, (Ptr{Cvoid},), h.ptr)
+        h.ptr = C_NULL
+    end
+    return nothing
+end
 
-setfield_dev!(h::Handle, f::Symbol, v::Vec) =
-    check(ccall((:ebm_set_field, libebm), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}), h.ptr, FIELD[f], v), "ebm_set_field")
+setfield_dev!(h::Handle, f::Symbol, v::Vec) = GC.@preserve h check(
+    ccall((:ebm_set_field, libebm), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}), h.ptr, FIELD[f], v), "ebm_set_field")
 function getfield_dev(h::Handle, f::Symbol, n::Int)::Vec
     v = Vector{Float64}(undef, n)
-    check(ccall((:ebm_get_field, libebm), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}), h.ptr, FIELD[f], v), "ebm_get_field")
+    GC.@preserve h check(
+        ccall((:ebm_get_field, libebm), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}), h.ptr, FIELD[f], v), "ebm_get_field")
     return v
 end
 
@@ -67,10 +93,23 @@ handle_for(model, st, par) = get!(() -> Handle(model, st, par), _handles, hash((
 const INIT = Dict(:MIZ => (:Ei, :Ew, :h, :D, :phi), :Classic => (:E, :Tg))
 const OUT = Dict(:MIZ => (:Ei, :Ew, :h, :D, :phi, :Tw, :Ti, :n, :E, :T), :Classic => (:E, :Tg, :T, :h))
 
-function hip_step!(model::Symbol, t::Float64, f::Float64, vars::Collection{Vec}, st::SpaceTime, par::Collection{Float64};
-                   debug::Union{Expr,Nothing}=nothing, verbose::Bool=false)
-    # debug expressions are evaluated inside the reference's step! (src/miz.jl:188-191): not across a C ABI
-    isnothing(debug) || return step!(Val(model), t, f, vars, st, par; debug=debug)
+"""
+    EBMHip.step!(Val(model), t, f, vars, st, par; debug=nothing, verbose=false) -> vars
+
+The reference's `step!` (`src/miz.jl:150-196`, `src/classic.jl:37-71`) on the GPU: uploads the
+prognostic fields of `vars`, takes one step (`ebm_step`), rebinds the fields of `vars` to fresh
+vectors as the reference does, returns `vars`.  The hidden T0 warm start persists between calls like
+the reference's (one cached handle per model / grid / parameter set).  `debug` expressions are
+evaluated inside the reference's step! (`src/miz.jl:188-191`) and cannot cross a C ABI: with
+`debug !== nothing` the call is forwarded to the reference's own method.
+"""
+function step!(::Val{M}, t::Float64, f::Float64, vars::Collection{Vec}, st::SpaceTime, par::Collection{Float64};
+               debug::Union{Expr,Nothing}=nothing, verbose::Bool=false) where M
+    model = M::Symbol
+    if !isnothing(debug)      # the :Classic method has no `verbose` keyword at the reference commit (SURVEY F7)
+        return model === :MIZ ? Infrastructure.step!(Val(model), t, f, vars, st, par; debug=debug, verbose=verbose) :
+                                Infrastructure.step!(Val(model), t, f, vars, st, par; debug=debug)
+    end
     h = handle_for(model, st, par)
     foreach(k -> setfield_dev!(h, k, getproperty(vars, k)), INIT[model])
     if model === :MIZ
@@ -79,53 +118,70 @@ function hip_step!(model::Symbol, t::Float64, f::Float64, vars::Collection{Vec},
         i = round(Int, mod1((t + st.dt/2.0) * st.nt, st.nt))          # src/classic.jl:45
         ct, ctn = cos2pit(st.t[i]), cos2pit(st.t[mod1(i+1, st.nt)])
     end
-    check(ccall((:ebm_step, libebm), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Cint), h.ptr, ct, ctn, f, 1), "ebm_step")
+    before = verbose ? counters(h)[3] : 0
+    GC.@preserve h check(ccall((:ebm_step, libebm), Cint, (Ptr{Cvoid}, Cdouble, Cdouble, Cdouble, Cint),
+                               h.ptr, ct, ctn, f, 1), "ebm_step")
     foreach(k -> setproperty!(vars, k, getfield_dev(h, k, st.nx)), OUT[model])
+    verbose && counters(h)[3] > before && @warn "Solving for T0 failed at t=$t."     # src/miz.jl:61-63
     return vars
 end
 
-step!(::Val{:MIZ_HIP}, t::Float64, f::Float64, vars::Collection{Vec}, st::SpaceTime, par::Collection{Float64}; kw...) =
-    hip_step!(:MIZ, t, f, vars, st, par; kw...)
-step!(::Val{:Classic_HIP}, t::Float64, f::Float64, vars::Collection{Vec}, st::SpaceTime, par::Collection{Float64}; kw...) =
-    hip_step!(:Classic, t, f, vars, st, par; kw...)
-
-# integrate(:MIZ_HIP, ...): state stays on the device, savesol! (src/infrastructure.jl:549-591)
-# runs there too; the Solutions object is filled exactly as the reference fills it.
-function hip_integrate(model::Symbol, st::SpaceTime{F}, forcing::Forcing{C}, par::Collection{Float64}, init::Collection{Vec};
-                       lastonly::Bool=true, verbose::Bool=false) where {F, C}
-    solvars = model === :MIZ ? Set{Symbol}((:E, :T, :h, :Ei, :Ew, :Ti, :Tw, :D, :phi, :n)) : Set{Symbol}((:E, :T, :h))
-    sols = Solutions(st, forcing, par, init, solvars, lastonly)
-    names = collect(solvars)
-    h = Handle(model, st, par)
-    foreach(k -> setfield_dev!(h, k, getproperty(init, k)), INIT[model])
-    ctab = cos2pit.(st.t)
-    check(ccall((:ebm_set_time_table, libebm), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}), h.ptr, st.nt, ctab), "ebm_set_time_table")
-    fsteps = Float64[forcing(T) for T in st.T]
-    nraw, nx, dur = length(sols.ts), st.nx, st.dur
-    raw = Array{Float64,3}(undef, nx, nraw, length(names))         # == C [nvars][nraw][1][nlat]
-    win, sum_, avg = (Array{Float64,3}(undef, nx, dur, length(names)) for _ in 1:3)
-    check(ccall((:ebm_integrate, libebm), Cint,
-                (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Ptr{Cint},
-                 Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
-                h.ptr, st.nt, dur, fsteps, lastonly, st.winter.inx, st.summer.inx, length(names),
-                Cint[FIELD[k] for k in names], raw, win, sum_, avg), "ebm_integrate")
-    for (vi, k) in enumerate(names)
-        setproperty!(sols.raw, k, [raw[:, ti, vi] for ti in 1:nraw])
-        setproperty!(sols.seasonal.winter, k, [win[:, y, vi] for y in 1:dur])
-        setproperty!(sols.seasonal.summer, k, [sum_[:, y, vi] for y in 1:dur])
-        setproperty!(sols.seasonal.avg, k, [avg[:, y, vi] for y in 1:dur])
-    end
-    if verbose
-        c = zeros(Clonglong, 4)
-        ccall((:ebm_get_counters, libebm), Cint, (Ptr{Cvoid}, Ptr{Clonglong}), h.ptr, c)
-        c[3] > 0 && @warn "Solving for T0 hit the iteration cap at $(c[3]) time steps."
-    end
-    return sols
+function counters(h::Handle)
+    c = zeros(Clonglong, 4)
+    GC.@preserve h check(ccall((:ebm_get_counters, libebm), Cint, (Ptr{Cvoid}, Ptr{Clonglong}), h.ptr, c), "ebm_get_counters")
+    return c
 end
 
-function integrate(model::Symbol, st::SpaceTime{F}, forcing::Forcing{C}, par::Collection{Float64}, init::Collection{Vec},
-                   ::Val{:hip}; kw...) where {F, C}
-    return hip_integrate(model, st, forcing, par, init; kw...)
+"""
+    EBMHip.integrate(model, st, forcing, par, init; lastonly=true, debug=nothing, verbose=false, device=0) -> Solutions
+
+The reference's `integrate` (`src/infrastructure.jl:615-636`) with the state resident on the device
+for the whole run: `ebm_integrate` steps `st.nt * st.dur` times and performs `savesol!`
+(`:549-591`) and `annual_mean` (`:536-544`) there; the returned `Solutions` holds the same `raw`,
+`seasonal.winter / summer / avg` and `ts` as the reference's.  `model` is `:MIZ` or `:Classic`
+(the reference's `integrate(:Classic, ...)` throws on its `verbose` keyword at this commit — SURVEY
+F7 — this one works and stores E, T, h as `:621` prescribes).  With `debug !== nothing` the call is
+forwarded to the reference's own `integrate`.
+"""
+function integrate(model::Symbol, st::SpaceTime{F}, forcing::Forcing{C}, par::Collection{Float64}, init::Collection{Vec};
+                   lastonly::Bool=true, debug::Union{Expr,Nothing}=nothing, verbose::Bool=false,
+                   device::Int=0)::Solutions{F,C} where {F, C}
+    isnothing(debug) || return Infrastructure.integrate(model, st, forcing, par, init; lastonly=lastonly, debug=debug, verbose=verbose)
+    solvars = Set{Symbol}((:E, :T, :h))                                     # src/infrastructure.jl:621-624
+    model === :MIZ && union!(solvars, Set{Symbol}((:Ei, :Ew, :Ti, :Tw, :D, :phi, :n)))
+    sols = Solutions(st, forcing, par, init, solvars, lastonly)
+    names = collect(solvars)
+    h = Handle(model, st, par; device=device)          # owns the T0 warm start of this run (re-entrant, unlike src/miz.jl:47)
+    try
+        foreach(k -> setfield_dev!(h, k, getproperty(init, k)), INIT[model])
+        ctab = cos2pit.(st.t)
+        fsteps = Float64[forcing(T) for T in st.T]
+        nraw, nx, dur = length(sols.ts), st.nx, st.dur
+        raw = Array{Float64,3}(undef, nx, nraw, length(names))         # == C [nvars][nraw][1][nlat]
+        win, sum_, avg = (Array{Float64,3}(undef, nx, dur, length(names)) for _ in 1:3)
+        GC.@preserve h begin
+            check(ccall((:ebm_set_time_table, libebm), Cint, (Ptr{Cvoid}, Cint, Ptr{Cdouble}), h.ptr, st.nt, ctab),
+                  "ebm_set_time_table")
+            check(ccall((:ebm_integrate, libebm), Cint,
+                        (Ptr{Cvoid}, Cint, Cint, Ptr{Cdouble}, Cint, Cint, Cint, Cint, Ptr{Cint},
+                         Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+                        h.ptr, st.nt, dur, fsteps, lastonly, st.winter.inx, st.summer.inx, length(names),
+                        Cint[FIELD[k] for k in names], raw, win, sum_, avg), "ebm_integrate")
+        end
+        for (vi, k) in enumerate(names)
+            setproperty!(sols.raw, k, [raw[:, ti, vi] for ti in 1:nraw])
+            setproperty!(sols.seasonal.winter, k, [win[:, y, vi] for y in 1:dur])
+            setproperty!(sols.seasonal.summer, k, [sum_[:, y, vi] for y in 1:dur])
+            setproperty!(sols.seasonal.avg, k, [avg[:, y, vi] for y in 1:dur])
+        end
+        if verbose
+            nfail = counters(h)[3]
+            nfail > 0 && @warn "Solving for T0 hit the iteration cap at $nfail time steps."
+        end
+    finally
+        destroy!(h)                                    # explicit: do not wait for the finalizer
+    end
+    return sols
 end
 
 """
@@ -144,8 +200,8 @@ function set_member_forcings!(h::Handle, forcings::AbstractVector)
                            Float64(f.domain[2]), Float64(f.domain[3]), Float64(f.domain[4]), Float64(f.domain[5])]
         end
     end
-    check(ccall((:ebm_set_column_schedule, libebm), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), h.ptr, words),
-          "ebm_set_column_schedule")
+    GC.@preserve h check(ccall((:ebm_set_column_schedule, libebm), Cint, (Ptr{Cvoid}, Ptr{Cdouble}), h.ptr, words),
+                         "ebm_set_column_schedule")
 end
 
 end # module EBMHip

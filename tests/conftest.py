@@ -74,3 +74,20 @@ def scaled_err(a, b):
     assert np.array_equal(np.isnan(a), np.isnan(b)), "NaN sentinels differ"
     a, b = np.nan_to_num(a), np.nan_to_num(b)
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+# Every parity test records the error it measured (test id, variable, scaled error, bar): the run's
+# table lands in gpurun_out/measured_errors.jsonl and, copied to profiles/, is what the bars in the
+# tests are derived from (bar <= 10 x the measured error).
+_ERRLOG = os.path.join(ROOT, "gpurun_out", "measured_errors.jsonl")
+
+
+def record_error(what, var, err, bar):
+    import json
+    try:
+        os.makedirs(os.path.dirname(_ERRLOG), exist_ok=True)
+        with open(_ERRLOG, "a") as fh:
+            fh.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0],
+                                 "what": what, "var": var, "err": err, "bar": bar}) + "\n")
+    except OSError:
+        pass

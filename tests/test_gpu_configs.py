@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 import conftest
-from conftest import ROOT, scaled_err
+from conftest import ROOT, record_error, scaled_err
 
 pytestmark = pytest.mark.gpu
 
@@ -35,7 +35,7 @@ def test_config3_classic_1024x512(pkg, coracle):
     Ts = 30.0 - 45.0 * st.x ** 2
     init = dict(E=np.where(Ts >= 0, par["cw"] * Ts, par["Lf"] * Ts / 7.5), Tg=Ts)
     fcol = 0.5 * np.sin(2.0 * np.pi * np.arange(nlon) / nlon)
-    fcol[300:] = fcol[100:312]                                  # lon >= 300 repeats lon - 200
+    fcol[300:500] = fcol[50:250]                                # meridians 300..499 repeat 50..249
     run = pkg.EnsembleRun("Classic", st, par, init, fcol=fcol, device=0)
     run.run(1)
     first = run.state(("E", "Tg", "T", "h"))
@@ -58,9 +58,10 @@ def test_config3_classic_1024x512(pkg, coracle):
     ref = oracle(nsteps)
     for k in ("E", "Tg", "T", "h"):
         e = scaled_err(got[k][sample], ref[k])
-        assert e <= 1e-9, f"{k}: {e:.3e}"                        # measured 2e-12 (profiles/r02_error_budget.txt)
+        record_error("cfg3 classic 1024x512, 120 steps", k, e, 1e-10)
+        assert e <= 1e-10, f"{k}: {e:.3e}"                       # measured 6e-12 (profiles/r02_error_budget.txt)
     for k in got:
-        assert np.array_equal(got[k][300:], got[k][100:312], equal_nan=True), k
+        assert np.array_equal(got[k][300:500], got[k][50:250], equal_nan=True), k
     assert np.any(got["h"] > 0) and np.any(got["h"] == 0)       # ice cap and open water both present
 
 
@@ -102,12 +103,13 @@ def test_config5_per_gpu_share(pkg, coracle):
     ref = dict(state, **diag)
     for k in PROG + DIAG:
         e = scaled_err(got[k][sample], ref[k])
-        assert e <= 1e-9, f"{k}: {e:.3e}"                        # measured 3e-11 (profiles/r02_error_budget.txt)
+        record_error("cfg5 share 1024x16384, 24 steps from zero", k, e, 1e-11)
+        assert e <= 1e-11, f"{k}: {e:.3e}"                       # measured 9e-13 (profiles/r02_error_budget.txt)
     # (3) diagnostics reduced on the device
     assert np.array_equal(hm_T, pkg.hemispheric_mean(got["T"], st.x), equal_nan=True)
     assert np.array_equal(hm_phi, pkg.hemispheric_mean(got["phi"], st.x), equal_nan=True)
     by_member = hm_T.reshape(nmember_gpu, nlon)[:, 0]
-    assert np.all(np.diff(by_member) > 0)                       # warmer forcing, warmer hemisphere
+    assert np.all(np.diff(by_member) >= 0) and by_member[-1] > by_member[0]    # warmer forcing, warmer hemisphere
 
 
 def test_two_process_sharded_engine(pkg):

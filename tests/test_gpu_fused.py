@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import load_golden, scaled_err
+from conftest import record_error, scaled_err
 
 pytestmark = pytest.mark.gpu
 
@@ -73,7 +73,7 @@ def test_fused_run_equals_single_steps(pkg, kind, nlat, ncol, nt, K):
             cnt[mode] = eng.counters()
     for k in ALL:
         assert np.array_equal(out["single"][k], out["fused"][k], equal_nan=True), k
-    assert np.any(out["single"]["phi"] > 0) and np.any(out["single"]["phi"] == 0)
+    assert np.any(out["single"]["phi"] > 0) and np.any(out["single"]["Ew"] != 0)
     assert cnt["fused"]["steps"] == cnt["single"]["steps"] == nsteps
     assert cnt["fused"]["solves"] == cnt["single"]["solves"] and cnt["fused"]["cap_hits"] == 0
     assert cnt["single"]["launches"] == nsteps
@@ -150,7 +150,9 @@ def test_fused_run_matches_oracle(pkg, coracle):
         cnt = eng.counters()
     ref = dict(state, **diag)
     for k in ALL:
-        assert scaled_err(got[k], ref[k]) <= 1e-10 * (nlat / 256.0) ** 2, k
+        e = scaled_err(got[k], ref[k])
+        record_error("fused 1440 x1, 60 steps from zero", k, e, 1e-10)
+        assert e <= 1e-10, k
     assert cnt["solves"] == ocnt[0] and cnt["launches"] == 3
 
 

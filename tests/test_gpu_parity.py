@@ -1,37 +1,41 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the oracle.
 
-Tolerances (fp64).  Everything except the tridiagonal solves is a bit-exact restatement, so
-from IDENTICAL inputs one step differs from the oracle only through the T0 (or Tg) solve,
-whose forward error is cond(J)*eps: measured <= 1e-13 at nlat = 180, <= 1e-12 at nlat = 4096.
-    TOL_STEP  = 1e-11  one step from a golden / oracle state (scaled error |a-b|/max(1,|b|))
-    TOL_SHORT = 1e-10  short trajectories (<= 50 steps) — BASELINE.json's stated bar
+Tolerances (fp64) are MEASURED, not allowed for.  Everything except the tridiagonal solves is a
+bit-exact restatement, so from identical inputs one step differs from the oracle only through the
+T0 (or Tg) solve, whose forward error is cond(J)*eps for ANY backward-stable algorithm (the oracle's
+Thomas, the reference's dense LU, the GPU's partition + cyclic reduction); along a trajectory that
+difference is then carried by the model's own dynamics.  Every comparison below records the error it
+observed (conftest.record_error -> gpurun_out/measured_errors.jsonl; the round's table is committed
+as profiles/r02_measured_errors.jsonl) and its bar is
+
+    bar = min(10 x the error measured on MI355X, the bar BASELINE.json / the reference test gives)
+
+with the measured value written next to it.  No bar exceeds 1e-10 — BASELINE.json's figure and two
+orders inside the reference test's own isapprox rtol 1.49e-8 (test/runtests.jl:46) — except the
+year-long run on the identity grid (TOL_YEAR) and the shadowing tests, whose bars come from the
+oracle's own sensitivity.  profiles/r02_error_budget.txt adds, per configuration, how far the GPU and
+the fp64 oracle EACH are from the same model evaluated in 80-bit extended precision: the GPU is as
+close to it as the oracle is (test_gpu_error_budget.py).
 Long trajectories: the reference's own test configuration (sin grid, nx = 180, nt = 2000) is
 chaotic — a 1-ulp perturbation of the ORACLE grows to O(1) within the year (DESIGN.md
 "Sensitivity") — so a year-long comparison is only meaningful on the identity grid, where the
-same perturbation stays below 1e-9; there the bar is TOL_YEAR = 1e-7.
-Conditioning: the T0 Jacobian couples neighbours with D/dx^2 ~ 0.25-0.6*nlat^2 against a
-diagonal excess k/h+B ~ 3-22, so cond(J) ~ nlat^2 and ANY backward-stable solve (the oracle's
-Thomas, the reference's dense LU, the GPU's partition + cyclic reduction) carries a forward
-error ~cond*eps: ~1e-13 at nlat=180, ~1e-10 at nlat=1024.  Tolerances for nlat > 256 are
-therefore scaled by (nlat/256)^2 (`size_tol`), and test_t0_solve_accuracy_extended_precision
-checks the GPU's T0 against an 80-bit solve directly.
+same perturbation stays below 1e-9.
 NaN sentinels (src/miz.jl:193-194) must coincide exactly.
 """
 import numpy as np
 import pytest
 
-from conftest import load_golden, scaled_err
+from conftest import load_golden, record_error, scaled_err
 
 pytestmark = pytest.mark.gpu
 
-TOL_STEP, TOL_SHORT, TOL_YEAR = 1e-11, 1e-10, 1e-7
+TOL_STEP = 1e-11     # one step from a golden state: measured <= 2.1e-12 (identity grid, step 1000)
+TOL_SHORT = 1e-10    # BASELINE.json's bar; trajectories of <= 50 steps at nlat <= 257 measure <= 5.7e-11
+TOL_TRAJ10 = 1e-12   # the reference test's own comparison point (step 10 from zero): measured 8.5e-14
+TOL_YEAR = 1e-7      # 2000 steps on the identity grid: measured 7.3e-9
 PROG = ("Ei", "Ew", "h", "D", "phi")
 DIAG = ("Tw", "Ti", "n", "E", "T")
 ALL = PROG + ("T0",) + DIAG
-
-
-def size_tol(tol, nlat):
-    return tol * max(1.0, (nlat / 256.0) ** 2)
 
 
 def make_engine(pkg, model, st, par, ncol=1):
@@ -44,9 +48,11 @@ def ctab(pkg, st):
 
 
 def check_all(got, ref, tol, names=ALL, what=""):
+    errs = {k: scaled_err(got[k], ref[k]) for k in names}
+    worst = max(errs, key=errs.get)
+    record_error(what, worst, errs[worst], tol)
     for k in names:
-        e = scaled_err(got[k], ref[k])
-        assert e <= tol, f"{what}: {k} scaled error {e:.3e} > {tol:.1e}"
+        assert errs[k] <= tol, f"{what}: {k} scaled error {errs[k]:.3e} > {tol:.1e}"
 
 
 # ---- golden fixtures: the reference test's configuration -------------------------------------
@@ -64,7 +70,7 @@ def test_miz_trajectory_from_zero_matches_golden(pkg, kind):
             eng.run(done, s - done)
             done = s
             got = {k: v[0] for k, v in eng.get_state(ALL).items()}
-            check_all(got, {k: g[f"s{s}_{k}"] for k in ALL}, TOL_SHORT, what=f"{kind} step {s}")
+            check_all(got, {k: g[f"s{s}_{k}"] for k in ALL}, TOL_TRAJ10, what=f"{kind} step {s}")
         assert eng.counters()["cap_hits"] == 0
 
 
@@ -134,6 +140,7 @@ def test_miz_year_on_reference_config_shadows_the_oracle(pkg, coracle):
             done = s
             got = {k: v[0] for k, v in eng.get_state(ALL).items()}
             dist = max(scaled_err(got[k], ref[s][k]) for k in PROG)
+            record_error(f"reference config shadow step {s} (envelope {envelope[s]:.2e})", "PROG", dist, max(TOL_SHORT, 5.0 * envelope[s]))
             assert dist <= max(TOL_SHORT, 5.0 * envelope[s]), f"step {s}: {dist:.2e} vs envelope {envelope[s]:.2e}"
         assert eng.counters()["cap_hits"] == 0
     # year-end climate
@@ -170,7 +177,8 @@ def test_headline_meridians_shadow_the_oracle(pkg, coracle):
             got = eng.get_state(PROG)
             dist = max(scaled_err(got[k], ref[k]) for k in PROG)
             envelope = max(scaled_err(alt[k], ref[k]) for k in PROG)
-            assert dist <= max(size_tol(TOL_SHORT, nlat), 5.0 * envelope), f"step {s}: {dist:.2e} vs {envelope:.2e}"
+            record_error(f"headline shadow step {s} (envelope {envelope:.2e})", "PROG", dist, max(TOL_SHORT, 5.0 * envelope))
+            assert dist <= max(TOL_SHORT, 5.0 * envelope), f"step {s}: {dist:.2e} vs {envelope:.2e}"
         assert eng.counters()["cap_hits"] == 0
 
 
@@ -245,24 +253,26 @@ def test_t0_solve_accuracy_extended_precision(pkg, oracle, coracle, kind, nlat, 
     assert np.array_equal(truth < p["Tm"], sset)
     e_gpu = float(np.max(np.abs(T0_gpu - truth) / np.maximum(1.0, np.abs(truth))))
     e_cpu = float(np.max(np.abs(T0_cpu - truth) / np.maximum(1.0, np.abs(truth))))
-    bound = size_tol(1e-12, nlat)
+    bound = 1e-12                                            # measured 9.2e-14 (1024), 7.1e-14 (4096)
+    record_error(f"T0 vs 80-bit solve {kind} {nlat} (gpu)", "T0", e_gpu, bound)
+    record_error(f"T0 vs 80-bit solve {kind} {nlat} (oracle)", "T0", e_cpu, bound)
     assert e_gpu <= bound and e_cpu <= bound, (e_gpu, e_cpu)
     assert e_gpu <= 20 * e_cpu + 1e-14, (e_gpu, e_cpu)
 
 
 # ---- sizes, raggedness, many columns ----------------------------------------------------------
-@pytest.mark.parametrize("kind,nlat,ncol,nt,spin,nsteps", [
-    ("sin", 2, 1, 100, 0, 5),             # smallest legal grid
-    ("sin", 63, 3, 2000, 5, 20),          # less than one wave of chunks
-    ("sin", 255, 2, 8000, 10, 30),        # odd nlat: pitch padding, ragged last chunk
-    ("identity", 257, 2, 8000, 10, 30),
-    ("sin", 1000, 5, 60000, 20, 20),      # 256 threads, ragged
-    ("sin", 1440, 2, 131072, 50, 20),     # BASELINE configs[1]: 1-D MIZ, 1440 bands
-    ("identity", 1024, 8, 262144, 50, 20),  # nt: 2x the explicit stability limit cw dx^2/(2D)
-    ("sin", 4096, 6, 1048576, 50, 10),    # BASELINE configs[3] meridian length, 1024 threads: the maximum
-    ("sin", 4093, 2, 1048576, 20, 5),     # ragged at the maximum workgroup size
+@pytest.mark.parametrize("kind,nlat,ncol,nt,spin,nsteps,measured", [
+    ("sin", 2, 1, 100, 0, 5, 1.8e-16),             # smallest legal grid
+    ("sin", 63, 3, 2000, 5, 20, 2.8e-13),          # less than one wave of chunks
+    ("sin", 255, 2, 8000, 10, 30, 1.4e-11),        # odd nlat: pitch padding, ragged last chunk
+    ("identity", 257, 2, 8000, 10, 30, 5.7e-11),
+    ("sin", 1000, 5, 60000, 20, 20, 6.7e-12),      # 256 threads, ragged
+    ("sin", 1440, 2, 131072, 50, 20, 2.3e-12),     # BASELINE configs[1]: 1-D MIZ, 1440 bands
+    ("identity", 1024, 8, 262144, 50, 20, 1.2e-13),  # nt: 2x the explicit stability limit cw dx^2/(2D)
+    ("sin", 4096, 6, 1048576, 50, 10, 2.6e-13),    # BASELINE configs[3] meridian length, 1024 threads: the maximum
+    ("sin", 4093, 2, 1048576, 20, 5, 1.1e-13),     # ragged at the maximum workgroup size
 ])
-def test_miz_sizes_vs_oracle(pkg, coracle, kind, nlat, ncol, nt, spin, nsteps):
+def test_miz_sizes_vs_oracle(pkg, coracle, kind, nlat, ncol, nt, spin, nsteps, measured):
     """Spin up with the oracle (ice edge, open water and T0 solve all live), hand the state to
     the GPU, advance both, compare.  Per-column forcing differs per column."""
     st = pkg.SpaceTime(kind, nlat, nt, 1)
@@ -283,7 +293,7 @@ def test_miz_sizes_vs_oracle(pkg, coracle, kind, nlat, ncol, nt, spin, nsteps):
     diag, ocnt = coracle.miz_run(kid, st.x, dict(par), st.dt, ct[spin:spin + nsteps], np.zeros(nsteps), fcol, state)
     ref = dict(state)
     ref.update(diag)
-    check_all(got, ref, size_tol(TOL_SHORT, nlat), what=f"{kind} {nlat}x{ncol}")
+    check_all(got, ref, min(TOL_SHORT, 10.0 * measured), what=f"{kind} {nlat}x{ncol}")
     assert cnt["solves"] == ocnt[0] and cnt["cap_hits"] == 0     # same active-set iteration path
 
 
@@ -381,6 +391,11 @@ def test_randomized_states_one_step(pkg, coracle, seed):
     D = np.where(ice, rng.choice([0.0, par["Dmin"], 10.0, par["Dmax"]], size=shape), 0.0)
     Ei = -par["Lf"] * h * phi * np.where(rng.random(shape) < 0.8, 1.0, rng.uniform(0.0, 2.0, shape))
     Ew = par["cw"] * rng.uniform(-0.5, 12.0, shape) * (1.0 - 0.9 * phi)
+    if seed % 6 != 5:
+        # a saturated cell (phi == 1) with water enthalpy left in it has Tw = Ew/0 = Inf, which turns its
+        # whole column's T0 system into NaNs: kept in every sixth seed (NaN propagation), removed in the
+        # others so that the comparison is one of finite numbers (0/0 -> NaN -> 0, src/miz.jl:157)
+        Ew = np.where(phi == 1.0, 0.0, Ew)
     T0 = rng.uniform(-20.0, 5.0, shape)
     state = dict(Ei=Ei, Ew=Ew, h=h, D=D, phi=phi, T0=T0)
     state = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in state.items()}
@@ -401,7 +416,10 @@ def test_randomized_states_one_step(pkg, coracle, seed):
     ref.update(diag)
     for k in ALL:
         assert np.array_equal(np.isnan(got[k]), np.isnan(ref[k])), f"{k}: NaN pattern (seed {seed})"
-    check_all(got, ref, size_tol(TOL_STEP, nlat) * 10, what=f"seed {seed} {kind} {nlat}x{ncol}")
+    finite = float(np.mean(np.isfinite(ref["T0"])))
+    if seed % 6 != 5:
+        assert finite == 1.0, finite                              # a comparison of numbers, not of NaN patterns
+    check_all(got, ref, 1.2e-11, what=f"seed {seed} {kind} {nlat}x{ncol} finite {finite:.2f}")   # measured <= 1.2e-12
     assert cnt["solves"] == ocnt[0], (cnt, ocnt)
 
 
@@ -502,7 +520,8 @@ def test_classic_sizes_vs_oracle(pkg, coracle, nlat, ncol):
     out = coracle.classic_run(st.x, dict(par), st.dt, ct[idx], ct[(idx + 1) % st.nt], np.zeros(nsteps), fcol, state)
     ref = dict(state)
     ref.update(out)
-    check_all(got, ref, size_tol(TOL_SHORT, nlat), names=("E", "Tg", "T", "h"), what=f"classic {nlat}x{ncol}")
+    measured = {1024: 8.2e-12, 333: 5.8e-14}[nlat]
+    check_all(got, ref, 10.0 * measured, names=("E", "Tg", "T", "h"), what=f"classic {nlat}x{ncol}")
 
 
 @pytest.mark.parametrize("seed", range(8))
@@ -533,7 +552,8 @@ def test_classic_randomized_states_one_step(pkg, coracle, seed):
     ref.update(out)
     for k in ("E", "T", "h"):                                  # pointwise physics: bit-exact
         assert np.array_equal(got[k], ref[k], equal_nan=True), f"{k} (seed {seed})"
-    assert scaled_err(got["Tg"], ref["Tg"]) <= size_tol(TOL_STEP, nlat), f"Tg (seed {seed})"
+    record_error(f"classic fuzz seed {seed} nlat {nlat}", "Tg", scaled_err(got["Tg"], ref["Tg"]), 5e-14)
+    assert scaled_err(got["Tg"], ref["Tg"]) <= 5e-14, f"Tg (seed {seed})"      # measured <= 5.1e-15
 
 
 def test_device_division_is_ieee(pkg):
@@ -795,4 +815,4 @@ def test_full_size_4096x2048_properties(pkg, coracle):
     diag, _ = coracle.miz_run(1, st.x, dict(par), st.dt, ct, np.zeros(nsteps), fcol[sample], state)
     ref = dict(state)
     ref.update(diag)
-    check_all({k: got[k][sample] for k in ALL}, ref, size_tol(TOL_SHORT, nlat), what="4096x2048 sample")
+    check_all({k: got[k][sample] for k in ALL}, ref, 2e-11, what="4096x2048 sample")      # measured 2.0e-12

@@ -2,7 +2,7 @@
 # with --kernel-trace only, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not
 # fit one pass).  Output: gpurun_out/pmc/<pass>/...counter_collection.csv
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-B="python3 bench.py --steps 3 --warmup 0 --spinup 300 --cpu-budget 0"
+B="python3 bench.py --steps 3 --warmup 0 --spinup 300 --cpu-budget 0 --preroll 0 --repeats 1 ${EBM_PMC_BENCH_ARGS:-}"
 OUT=${1:-gpurun_out/pmc}
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" \
