@@ -102,11 +102,11 @@ constexpr int kCounterShards = 64;
 constexpr int kSchedWords = 9;     // base, peak, cool, rate up, rate down, domain[1..4]
 constexpr int kMaxNewton = 50;
 
-constexpr int kCells = 4;          // cells per thread (C): 32 contiguous bytes per lane and field
-constexpr int kMaxLat = 4096;      // one workgroup of <= 1024 threads owns a whole meridian
+constexpr int kMaxLat = 4096;      // one workgroup of <= 1024 threads x 4 cells owns a whole meridian
 constexpr int kFusedRegThreads = 512;   // up to here the fused-K kernel keeps the whole state in registers
 
-LaunchCfg choose_launch(int nlat);
+// force_cells: 0 = choose (4 cells per thread; 2 for a few short meridians), 2 / 4 = as told
+LaunchCfg choose_launch(int nlat, int ncol, int force_cells);
 hipError_t prepare_kernels(const LaunchCfg &cfg);   // raises the dynamic-LDS limit if needed
 // One workgroup per column.  mode: OutMode; OUT_LOOP runs a.nfused steps per launch.
 hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, hipStream_t s);
@@ -121,6 +121,6 @@ hipError_t launch_hemispheric_mean(const double *field, const double *x, int pit
                                    hipStream_t s);
 // annual_mean (src/infrastructure.jl:536-544): dst[col][k] = sum/nt with `sum` in the pair-split
 // layout of the step kernels, then sum = 0
-hipError_t launch_finish_mean(double *dst, double *sum, double nt, int ncol, int threads, hipStream_t s);
+hipError_t launch_finish_mean(double *dst, double *sum, double nt, int ncol, const LaunchCfg &cfg, hipStream_t s);
 
 }  // namespace ebm

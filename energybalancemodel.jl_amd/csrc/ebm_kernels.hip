@@ -575,9 +575,9 @@ __device__ __forceinline__ void save_pair(const StepArgs &a, size_t col_off, uns
 //
 // OUT (OutMode): what is written besides the prognostics (OUT_STATE, OUT_DIAG, OUT_SAVE).
 // TT: workgroup size, a compile-time constant (LDS offsets become immediates).
-template <int GRID, int OUT, int TT>
+template <int C, int GRID, int OUT, int TT>
 __global__ void __launch_bounds__(1024) miz_step_kernel(const StepArgs a) {
-    constexpr int C = kCells;
+    static_assert(C == 2 || C == 4, "cells per thread");
     static_assert(OUT == OUT_STATE || OUT == OUT_DIAG || OUT == OUT_SAVE, "per-step kernel");
     constexpr bool MAYDIAG = OUT != OUT_STATE;            // diagnostic stores compiled in
     extern __shared__ double smem[];
@@ -655,7 +655,13 @@ __global__ void __launch_bounds__(1024) miz_step_kernel(const StepArgs a) {
         atomicAdd(cnt, (unsigned long long)it);
         if (again) atomicAdd(cnt + 1, 1ull);
     }
-    cmask[t] = (unsigned short)smask;                     // new warm start, src/miz.jl:64
+    {
+        // (the lane index is made opaque so that the mask word's per-lane 64-bit address is formed here
+        // again instead of being kept — and spilled — across the solve)
+        unsigned tl = (unsigned)t;
+        asm volatile("" : "+v"(tl));
+        cmask[tl] = (unsigned short)smask;                // new warm start, src/miz.jl:64
+    }
     EBM_STAMP(6);
     EBM_STAMPW(2);                                        // per wave: phase D starts
 
@@ -722,7 +728,7 @@ __global__ void __launch_bounds__(1024) miz_step_kernel(const StepArgs a) {
             }
             o[q] = miz_cell_update(p, f, S, xk[i], dif, tb[i], q ? Ei2.y : Ei2.x, sEw[i * T], sh[i * T],
                                    q ? Dk2.y : Dk2.x, ph[i], sTw[i * T], xs[i]);
-            if (i == C - 2) {
+            if (C == 4 && i == C - 2) {
                 // L2 prefetch for the workgroup that follows this one on the XCD (column + a.prefetch):
                 // one 4-byte LDS-DMA load per 32-B sector of its phase-A inputs, issued once this
                 // thread's own loads have all been consumed and hidden under the last cell's
@@ -754,7 +760,11 @@ __global__ void __launch_bounds__(1024) miz_step_kernel(const StepArgs a) {
             d_.y = v1 ? o[1].q[qi] : 0.0;                                                          \
             EBM_STORE2(st + (slot_) * a.fstride + kp, d_);                                         \
         }
-        if (j == 0) {
+        if constexpr (C == 2) {
+            // two cells per thread (short meridians of latency-bound runs): the lane's 16 bytes are the
+            // pair; a wave's store already covers whole lines
+            EBM_PUT(S_Ei, Q_Ei) EBM_PUT(S_Ew, Q_Ew) EBM_PUT(S_h, Q_h) EBM_PUT(S_D, Q_D) EBM_PUT(S_phi, Q_phi)
+        } else if (j == 0) {
             // pair 0 of Ei, Ew -> P words; h, D, phi -> stash words of cells 0, 1 (all read already)
             park0[0] = v0 ? o[0].q[Q_Ei] : 0.0;  park0[T] = v1 ? o[1].q[Q_Ei] : 0.0;
             park0[2 * T] = v0 ? o[0].q[Q_Ew] : 0.0;  park0[3 * T] = v1 ? o[1].q[Q_Ew] : 0.0;
@@ -803,9 +813,9 @@ __global__ void __launch_bounds__(1024) miz_step_kernel(const StepArgs a) {
 // the last step if write_diag) and by the scalar loads of the per-step table.  Every step performs the
 // operations of miz_step_kernel in the same order on the same values: bit-identical results
 // (tests: test_fused_run_equals_single_steps).
-template <int GRID, int TT>
+template <int C, int GRID, int TT>
 __global__ void __launch_bounds__(TT) miz_fused_kernel(const StepArgs a) {
-    constexpr int C = kCells;
+    static_assert(C == 2 || C == 4, "cells per thread");
     constexpr int T = TT;
     extern __shared__ double smem[];
     const int t = threadIdx.x, col = blockIdx.x;
@@ -942,9 +952,9 @@ __global__ void __launch_bounds__(TT) miz_fused_kernel(const StepArgs a) {
 struct ClassicCellOut {
     double q[QC_COUNT];
 };
-template <int MODE>
+template <int C, int MODE>
 __global__ void __launch_bounds__(1024) classic_step_kernel(const StepArgs a) {
-    constexpr int C = kCells;
+    static_assert(C == 2 || C == 4, "cells per thread");
     constexpr bool LOOP = MODE == OUT_LOOP;
     extern __shared__ double smem[];
     const int T = blockDim.x, t = threadIdx.x, col = blockIdx.x;
@@ -1073,17 +1083,17 @@ __global__ void hemispheric_mean_kernel(const double *__restrict__ field, const 
 }
 // annual_mean (src/infrastructure.jl:536-544, crossmean src/utilities.jl:390-395): sum / nt, from
 // the pair-split layout of save_pair to the natural [col][pitch] one; the sum restarts at zero.
-__global__ void finish_mean_kernel(double *__restrict__ dst, double *__restrict__ sum, double nt, int threads) {
+__global__ void finish_mean_kernel(double *__restrict__ dst, double *__restrict__ sum, double nt, int threads,
+                                   int cells) {
     const int t = threadIdx.x, col = blockIdx.x;
-    const size_t base = (size_t)col * (size_t)threads * kCells;
-#pragma unroll
-    for (int j = 0; j < kCells / 2; ++j) {
+    const size_t base = (size_t)col * (size_t)threads * cells;
+    for (int j = 0; j < cells / 2; ++j) {
         double2 *sp = reinterpret_cast<double2 *>(sum + base + (size_t)(j * 2 * threads + 2 * t));
         const double2 s = *sp;
         double2 m;
         m.x = s.x / nt;
         m.y = s.y / nt;
-        *reinterpret_cast<double2 *>(dst + base + (size_t)(t * kCells + 2 * j)) = m;
+        *reinterpret_cast<double2 *>(dst + base + (size_t)(t * cells + 2 * j)) = m;
         double2 z;
         z.x = 0.0;
         z.y = 0.0;
@@ -1092,17 +1102,23 @@ __global__ void finish_mean_kernel(double *__restrict__ dst, double *__restrict_
 }
 
 // ---- host-side launchers ----------------------------------------------------------------------
-LaunchCfg choose_launch(int nlat) {
+// Cells per thread.  4 everywhere that throughput matters (32 contiguous bytes per lane and field).
+// A run of a few short meridians is latency-bound on a handful of waves: there 2 cells per thread put
+// twice as many SIMDs to work on every meridian (nlat <= 1024 so that the fused kernel still fits).
+LaunchCfg choose_launch(int nlat, int ncol, int force_cells) {
     LaunchCfg cfg{};
     if (nlat > kMaxLat) {
         cfg.threads = 0;
         return cfg;
     }
-    const int chunks = (nlat + kCells - 1) / kCells;
+    int cells = 4;
+    if (nlat <= 1024 && (long long)ncol * ((nlat + 255) / 256) <= 128) cells = 2;
+    if ((force_cells == 2 && nlat <= 1024) || force_cells == 4) cells = force_cells;
+    const int chunks = (nlat + cells - 1) / cells;
     cfg.threads = ((chunks + 63) / 64) * 64;
-    cfg.cells = kCells;
+    cfg.cells = cells;
     // 2 x 3T cyclic reduction + the MIZ stash of Ew, h, Tw (3 C T)
-    cfg.lds_bytes = sizeof(double) * (size_t)cfg.threads * (6 + 3 * (size_t)kCells);
+    cfg.lds_bytes = sizeof(double) * (size_t)cfg.threads * (6 + 3 * (size_t)cells);
     return cfg;
 }
 
@@ -1110,25 +1126,36 @@ namespace {
 
 using KernelFn = void (*)(const StepArgs);
 
-// Every workgroup size is compiled as a constant: T = 64 ... 1024 in steps of one wave.
-template <int GRID, int OUT>
+// Every workgroup size is compiled as a constant: T = 64 ... 1024 in steps of one wave (two cells per
+// thread: up to 512 threads).
+template <int C, int GRID, int OUT>
 KernelFn miz_kernel_for(int threads) {
     switch (threads) {
-#define EBM_CASE(TT) case TT: return miz_step_kernel<GRID, OUT, TT>;
+#define EBM_CASE(TT) case TT: return miz_step_kernel<C, GRID, OUT, TT>;
 #ifdef EBM_QUICK   // development builds (tests/tools/resource_usage.py -DEBM_QUICK): three sizes only
-        EBM_CASE(64) EBM_CASE(256) EBM_CASE(1024)
+        EBM_CASE(64) EBM_CASE(256) EBM_CASE(512)
 #else
         EBM_CASE(64) EBM_CASE(128) EBM_CASE(192) EBM_CASE(256) EBM_CASE(320) EBM_CASE(384) EBM_CASE(448) EBM_CASE(512)
-        EBM_CASE(576) EBM_CASE(640) EBM_CASE(704) EBM_CASE(768) EBM_CASE(832) EBM_CASE(896) EBM_CASE(960) EBM_CASE(1024)
 #endif
-#undef EBM_CASE
-        default: return nullptr;
+        default: break;
     }
+    if constexpr (C == 4) {
+        switch (threads) {
+#ifdef EBM_QUICK
+            EBM_CASE(1024)
+#else
+            EBM_CASE(576) EBM_CASE(640) EBM_CASE(704) EBM_CASE(768) EBM_CASE(832) EBM_CASE(896) EBM_CASE(960) EBM_CASE(1024)
+#endif
+            default: break;
+        }
+    }
+#undef EBM_CASE
+    return nullptr;
 }
-template <int GRID>
+template <int C, int GRID>
 KernelFn miz_fused_for(int threads) {
     switch (threads) {
-#define EBM_CASE(TT) case TT: return miz_fused_kernel<GRID, TT>;
+#define EBM_CASE(TT) case TT: return miz_fused_kernel<C, GRID, TT>;
 #ifdef EBM_QUICK
         EBM_CASE(64) EBM_CASE(256) EBM_CASE(512)
 #else
@@ -1138,25 +1165,31 @@ KernelFn miz_fused_for(int threads) {
         default: return nullptr;
     }
 }
-KernelFn miz_kernel(int grid_kind, int mode, int threads) {
-    if (mode == OUT_LOOP)     // meridians of more than 4*kFusedRegThreads cells have no fused kernel (nullptr)
-        return grid_kind == 0 ? miz_fused_for<0>(threads) : miz_fused_for<1>(threads);
+template <int C, int GRID>
+KernelFn miz_kernel_cg(int mode, int threads) {
     switch (mode) {
-        case OUT_STATE: return grid_kind == 0 ? miz_kernel_for<0, OUT_STATE>(threads) : miz_kernel_for<1, OUT_STATE>(threads);
-        case OUT_DIAG: return grid_kind == 0 ? miz_kernel_for<0, OUT_DIAG>(threads) : miz_kernel_for<1, OUT_DIAG>(threads);
-        case OUT_SAVE: return grid_kind == 0 ? miz_kernel_for<0, OUT_SAVE>(threads) : miz_kernel_for<1, OUT_SAVE>(threads);
+        case OUT_STATE: return miz_kernel_for<C, GRID, OUT_STATE>(threads);
+        case OUT_DIAG: return miz_kernel_for<C, GRID, OUT_DIAG>(threads);
+        case OUT_SAVE: return miz_kernel_for<C, GRID, OUT_SAVE>(threads);
+        case OUT_LOOP: return miz_fused_for<C, GRID>(threads);   // more than kFusedRegThreads threads: no fused kernel (nullptr)
         default: return nullptr;
     }
 }
-KernelFn classic_kernel(int mode) {
+KernelFn miz_kernel(int cells, int grid_kind, int mode, int threads) {
+    if (cells == 2) return grid_kind == 0 ? miz_kernel_cg<2, 0>(mode, threads) : miz_kernel_cg<2, 1>(mode, threads);
+    return grid_kind == 0 ? miz_kernel_cg<4, 0>(mode, threads) : miz_kernel_cg<4, 1>(mode, threads);
+}
+template <int C>
+KernelFn classic_kernel_c(int mode) {
     switch (mode) {
         case OUT_STATE:
-        case OUT_DIAG: return classic_step_kernel<OUT_STATE>;
-        case OUT_SAVE: return classic_step_kernel<OUT_SAVE>;
-        case OUT_LOOP: return classic_step_kernel<OUT_LOOP>;
+        case OUT_DIAG: return classic_step_kernel<C, OUT_STATE>;
+        case OUT_SAVE: return classic_step_kernel<C, OUT_SAVE>;
+        case OUT_LOOP: return classic_step_kernel<C, OUT_LOOP>;
         default: return nullptr;
     }
 }
+KernelFn classic_kernel(int cells, int mode) { return cells == 2 ? classic_kernel_c<2>(mode) : classic_kernel_c<4>(mode); }
 // LDS of a launch: the fused register kernel only needs the solve's buffers
 size_t miz_lds_bytes(const LaunchCfg &cfg, int mode) {
     if (mode == OUT_LOOP) return sizeof(double) * 6 * (size_t)cfg.threads;
@@ -1170,7 +1203,7 @@ hipError_t prepare_kernels(const LaunchCfg &cfg) {
     if (cfg.lds_bytes <= 64 * 1024) return hipSuccess;
     for (int grid = 0; grid < 2; ++grid)
         for (int mode = OUT_STATE; mode <= OUT_SAVE; ++mode) {       // the fused kernel needs 6T doubles <= 24 KiB
-            KernelFn fn = miz_kernel(grid, mode, cfg.threads);
+            KernelFn fn = miz_kernel(cfg.cells, grid, mode, cfg.threads);
             if (!fn) return hipErrorInvalidValue;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
@@ -1180,14 +1213,14 @@ hipError_t prepare_kernels(const LaunchCfg &cfg) {
 }
 
 hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, hipStream_t s) {
-    KernelFn fn = miz_kernel(grid_kind, mode, cfg.threads);
+    KernelFn fn = miz_kernel(cfg.cells, grid_kind, mode, cfg.threads);
     if (!fn) return hipErrorInvalidValue;
     fn<<<dim3(a.ncol), dim3(cfg.threads), miz_lds_bytes(cfg, mode), s>>>(a);
     return hipGetLastError();
 }
 
 hipError_t launch_classic_step(const StepArgs &a, int mode, const LaunchCfg &cfg, hipStream_t s) {
-    KernelFn fn = classic_kernel(mode);
+    KernelFn fn = classic_kernel(cfg.cells, mode);
     if (!fn) return hipErrorInvalidValue;
     fn<<<dim3(a.ncol), dim3(cfg.threads), sizeof(double) * 6 * (size_t)cfg.threads, s>>>(a);
     return hipGetLastError();
@@ -1203,8 +1236,8 @@ hipError_t launch_hemispheric_mean(const double *field, const double *x, int pit
     hemispheric_mean_kernel<<<ncol, 256, sizeof(double) * (size_t)nlat, s>>>(field, x, pitch, nlat, out);
     return hipGetLastError();
 }
-hipError_t launch_finish_mean(double *dst, double *sum, double nt, int ncol, int threads, hipStream_t s) {
-    finish_mean_kernel<<<ncol, threads, 0, s>>>(dst, sum, nt, threads);
+hipError_t launch_finish_mean(double *dst, double *sum, double nt, int ncol, const LaunchCfg &cfg, hipStream_t s) {
+    finish_mean_kernel<<<ncol, cfg.threads, 0, s>>>(dst, sum, nt, cfg.threads, cfg.cells);
     return hipGetLastError();
 }
 

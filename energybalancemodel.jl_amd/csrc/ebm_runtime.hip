@@ -314,7 +314,8 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(EBM_ERR_NO_DEVICE, "ebm_create: no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(EBM_ERR_ARG, "ebm_create: device index out of range");
-    ebm::LaunchCfg cfg = ebm::choose_launch(nlat);
+    const char *cv = std::getenv("EBM_CELLS_PER_THREAD");    // testing knob: 2 or 4 cells per thread
+    ebm::LaunchCfg cfg = ebm::choose_launch(nlat, ncol, cv ? std::atoi(cv) : 0);
     if (cfg.threads == 0)
         return fail(EBM_ERR_UNSUPPORTED, "ebm_create: nlat > 4096 is not supported (one workgroup owns a whole meridian)");
     HIPCHK(hipSetDevice(device));
@@ -565,7 +566,7 @@ int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double
     if (!h || nsteps < 0 || first_step < 0 || steps_per_launch < 1) return fail(EBM_ERR_ARG, "ebm_run_fused: bad argument");
     if (h->ttab.empty()) return fail(EBM_ERR_ARG, "ebm_run_fused: call ebm_set_time_table first");
     // the fused MIZ kernel keeps the whole state in registers: up to kFusedRegThreads threads per
-    // meridian (2048 cells); longer meridians are stepped one launch per step
+    // meridian (2048 cells at 4 per thread); longer meridians are stepped one launch per step
     if (steps_per_launch == 1 || (h->model == EBM_MODEL_MIZ && h->cfg.threads > ebm::kFusedRegThreads))
         return ebm_run(h, first_step, nsteps, f_steps, diag_last);
     HIPCHK(hipSetDevice(h->device));
@@ -698,7 +699,7 @@ int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int la
         } else if (ti == nt) {
             if (sums)
                 for (int v = 0; v < nvars; ++v) {
-                    EBM_TRY(ebm::launch_finish_mean(mean, sums + (size_t)v * npitch, (double)nt, h->ncol, h->cfg.threads, h->stream));
+                    EBM_TRY(ebm::launch_finish_mean(mean, sums + (size_t)v * npitch, (double)nt, h->ncol, h->cfg, h->stream));
                     EBM_TRY(snapshot_to_host(avg + ((size_t)v * dur + (year - 1)) * ncell, mean));
                     EBM_TRY(hipStreamSynchronize(h->stream));
                 }

@@ -64,6 +64,15 @@ def coracle():
     return c.COracle()
 
 
+@pytest.fixture(params=[2, 4], ids=["2cells", "4cells"])
+def cells(request, monkeypatch):
+    """Cells per thread of the launch geometry: the library picks 2 for a few short meridians
+    (latency-bound) and 4 otherwise; tests that take this fixture run under both (EBM_CELLS_PER_THREAD;
+    meridians of more than 1024 cells always use 4)."""
+    monkeypatch.setenv("EBM_CELLS_PER_THREAD", str(request.param))
+    return request.param
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

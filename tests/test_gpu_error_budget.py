@@ -36,6 +36,17 @@ MIZ_CASES = [
 ]
 
 
+@pytest.fixture(autouse=True)
+def _restore_geometry_knob():
+    """error_budget.miz_case sets EBM_CELLS_PER_THREAD (4: the geometry of every throughput-sized run)."""
+    old = os.environ.get("EBM_CELLS_PER_THREAD")
+    yield
+    if old is None:
+        os.environ.pop("EBM_CELLS_PER_THREAD", None)
+    else:
+        os.environ["EBM_CELLS_PER_THREAD"] = old
+
+
 @pytest.fixture(scope="module")
 def oracles():
     import __graft_entry__ as graft

@@ -45,11 +45,13 @@ def classic_init(pkg, st, par, ncol):
     ("sin", 2048, 3, 262144, 9),          # the largest meridian with a fused kernel (512 threads)
     ("sin", 2045, 2, 262144, 4),
 ])
-def test_fused_run_equals_single_steps(pkg, kind, nlat, ncol, nt, K):
+def test_fused_run_equals_single_steps(pkg, kind, nlat, ncol, nt, K, cells):
     """K steps per launch against one launch per step: same operations on the same values, so every
     field — prognostics, the T0 of the last step, the diagnostics, NaN sentinels — is bitwise equal.
     Varying per-step forcing, per-column offsets, a run length that is not a multiple of K, a start
     late in the year (time index wraps), state handed over between two fused calls."""
+    if cells == 2 and nlat > 1024:
+        pytest.skip("two cells per thread exist up to 1024-cell meridians")
     st = pkg.SpaceTime(kind, nlat, nt, 1)
     par = pkg.default_parameters("MIZ")
     nsteps = 3 * K + 5
@@ -99,7 +101,7 @@ def test_fused_run_with_column_schedules(pkg):
 
 
 @pytest.mark.parametrize("nlat,ncol,K", [(180, 2, 25), (1024, 3, 8), (333, 1, 100)])
-def test_fused_run_classic(pkg, nlat, ncol, K):
+def test_fused_run_classic(pkg, nlat, ncol, K, cells):
     """Classic model: E and Tg stay in registers across the K steps of a launch."""
     st = pkg.SpaceTime("identity", nlat, 2000, 1)
     par = pkg.default_parameters("Classic")
@@ -173,7 +175,7 @@ def sequential_mean(raw, nt):
     ("Classic", "identity", 180, 2, 400, 2),
     ("Classic", "identity", 333, 1, 500, 1),
 ])
-def test_integrate_saves_from_registers(pkg, model, kind, nlat, ncol, nt, dur):
+def test_integrate_saves_from_registers(pkg, model, kind, nlat, ncol, nt, dur, cells):
     """ebm_integrate takes the annual-mean sums and the raw snapshots from the step kernel's
     registers (one launch per step).  (1) avg == sequential sum of the raw snapshots / nt, bit for
     bit; (2) the last raw snapshot is the final state; (3) winter / summer snapshots are the raw

@@ -57,13 +57,14 @@ def check_all(got, ref, tol, names=ALL, what=""):
 
 # ---- golden fixtures: the reference test's configuration -------------------------------------
 @pytest.mark.parametrize("kind", ["sin", "identity"])
-def test_miz_trajectory_from_zero_matches_golden(pkg, kind):
+def test_miz_trajectory_from_zero_matches_golden(pkg, kind, cells):
     """test/runtests.jl:22-47: zero initial state, compare the state after step 10 (the index
     the reference test checks); also steps 1 and 2."""
     g = load_golden(f"miz_{kind}_180_2000.npz")
     st = pkg.SpaceTime(kind, 180, 2000, 1)
     assert np.array_equal(st.x, g["x"])
     with make_engine(pkg, "MIZ", st, pkg.default_parameters("MIZ")) as eng:
+        assert eng.launch_info()["cells_per_thread"] == cells
         eng.set_time_table(st.t)
         done = 0
         for s in (1, 2, 10):
@@ -76,7 +77,7 @@ def test_miz_trajectory_from_zero_matches_golden(pkg, kind):
 
 @pytest.mark.parametrize("kind", ["sin", "identity"])
 @pytest.mark.parametrize("s", [10, 100, 522, 1000, 1548, 1999])
-def test_miz_one_step_from_golden_state(pkg, kind, s):
+def test_miz_one_step_from_golden_state(pkg, kind, s, cells):
     """Load the oracle's state after step s (freeze-up, winter, melt season, year end), take
     ONE step on the GPU, compare with the oracle's state after step s+1."""
     g = load_golden(f"miz_{kind}_180_2000.npz")
@@ -272,9 +273,11 @@ def test_t0_solve_accuracy_extended_precision(pkg, oracle, coracle, kind, nlat, 
     ("sin", 4096, 6, 1048576, 50, 10, 2.6e-13),    # BASELINE configs[3] meridian length, 1024 threads: the maximum
     ("sin", 4093, 2, 1048576, 20, 5, 1.1e-13),     # ragged at the maximum workgroup size
 ])
-def test_miz_sizes_vs_oracle(pkg, coracle, kind, nlat, ncol, nt, spin, nsteps, measured):
+def test_miz_sizes_vs_oracle(pkg, coracle, kind, nlat, ncol, nt, spin, nsteps, measured, cells):
     """Spin up with the oracle (ice edge, open water and T0 solve all live), hand the state to
     the GPU, advance both, compare.  Per-column forcing differs per column."""
+    if cells == 2 and nlat > 1024:
+        pytest.skip("two cells per thread exist up to 1024-cell meridians")
     st = pkg.SpaceTime(kind, nlat, nt, 1)
     par = pkg.default_parameters("MIZ")
     kid = 0 if kind == "identity" else 1
@@ -284,6 +287,7 @@ def test_miz_sizes_vs_oracle(pkg, coracle, kind, nlat, ncol, nt, spin, nsteps, m
     if spin:
         coracle.miz_run(kid, st.x, dict(par), st.dt, ct[:spin], np.zeros(spin), fcol, state)
     with make_engine(pkg, "MIZ", st, par, ncol) as eng:
+        assert eng.launch_info()["cells_per_thread"] == cells
         eng.set_state(state)
         eng.set_column_forcing(fcol)
         eng.set_time_table(st.t)
@@ -370,11 +374,12 @@ def test_unsupported_and_bad_arguments(pkg):
 
 # ---- edge cases of the state ------------------------------------------------------------------
 @pytest.mark.parametrize("seed", range(24))
-def test_randomized_states_one_step(pkg, coracle, seed):
+def test_randomized_states_one_step(pkg, coracle, seed, monkeypatch):
     """Seeded fuzz: random grid length and kind, random (physically loose) states mixing open
     water, thin and thick ice, phi = 0 / 1 / in between, floes at Dmin / Dmax / 0, inconsistent
     Ei, random warm-start signs, random forcing and time of year, perturbed parameters.  One step
     on the GPU against the oracle from identical inputs; sentinels must coincide."""
+    monkeypatch.setenv("EBM_CELLS_PER_THREAD", "2" if seed % 2 else "4")      # both launch geometries
     rng = np.random.default_rng(1000 + seed)
     nlat = int(rng.choice([2, 3, 5, 17, 64, 65, 127, 180, 256, 300, 511, 777]))
     ncol = int(rng.integers(1, 5))
@@ -484,7 +489,7 @@ def test_columns_are_independent_and_deterministic(pkg):
 
 
 # ---- classic model ----------------------------------------------------------------------------
-def test_classic_matches_golden(pkg):
+def test_classic_matches_golden(pkg, cells):
     g = load_golden("classic_identity_180_2000.npz")
     st = pkg.SpaceTime("identity", 180, 2000, 1)
     with make_engine(pkg, "Classic", st, pkg.default_parameters("Classic")) as eng:
@@ -500,7 +505,7 @@ def test_classic_matches_golden(pkg):
 
 
 @pytest.mark.parametrize("nlat,ncol", [(1024, 16), (333, 3)])
-def test_classic_sizes_vs_oracle(pkg, coracle, nlat, ncol):
+def test_classic_sizes_vs_oracle(pkg, coracle, nlat, ncol, cells):
     """BASELINE configs[2] shape (1024 latitudes; columns = longitudes with perturbed forcing)."""
     st = pkg.SpaceTime("identity", nlat, 2000, 1)
     par = pkg.default_parameters("Classic")
@@ -525,7 +530,8 @@ def test_classic_sizes_vs_oracle(pkg, coracle, nlat, ncol):
 
 
 @pytest.mark.parametrize("seed", range(8))
-def test_classic_randomized_states_one_step(pkg, coracle, seed):
+def test_classic_randomized_states_one_step(pkg, coracle, seed, monkeypatch):
+    monkeypatch.setenv("EBM_CELLS_PER_THREAD", "2" if seed % 2 else "4")
     """Seeded fuzz of the classic step: random length, random enthalpies around zero (so that the
     Bool masks E > 0, E < 0, E >= 0, T0 < 0 all flip within a column, including E == 0 exactly),
     random ghost layer, forcing and time index."""

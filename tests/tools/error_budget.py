@@ -42,7 +42,10 @@ def worst(x, y, names):
     return errs[k][0], k, all(v[1] for v in errs.values())
 
 
-def miz_case(pkg, co, cl, kind, nlat, ncol, nt, spin, checkpoints, fcol_amp=2.0):
+def miz_case(pkg, co, cl, kind, nlat, ncol, nt, spin, checkpoints, fcol_amp=2.0, cells=4):
+    """cells: launch geometry of the GPU run (4 = what every throughput-sized workload uses; 2 = what
+    the library picks for a few short meridians)."""
+    os.environ["EBM_CELLS_PER_THREAD"] = str(cells)
     st = pkg.SpaceTime(kind, nlat, nt, 1)
     par = pkg.default_parameters("MIZ")
     kid = 0 if kind == "identity" else 1
@@ -73,7 +76,8 @@ def miz_case(pkg, co, cl, kind, nlat, ncol, nt, spin, checkpoints, fcol_amp=2.0)
     return rows
 
 
-def classic_case(pkg, co, cl, nlat, ncol, checkpoints):
+def classic_case(pkg, co, cl, nlat, ncol, checkpoints, cells=4):
+    os.environ["EBM_CELLS_PER_THREAD"] = str(cells)
     st = pkg.SpaceTime("identity", nlat, 2000, 1)
     par = pkg.default_parameters("Classic")
     Ts = 30.0 - 45.0 * st.x ** 2
@@ -111,6 +115,7 @@ def main():
           f"{'GPU vs oracle, prognostics':>28s} NaNs")
     cases = [
         ("MIZ sin 180 x1 nt=2000 from zero (reference test)", lambda: miz_case(pkg, co, cl, "sin", 180, 1, 2000, 0, (1, 2, 10, 50))),
+        ("MIZ sin 180 x1 nt=2000 from zero, 2 cells per thread", lambda: miz_case(pkg, co, cl, "sin", 180, 1, 2000, 0, (1, 2, 10, 50), cells=2)),
         ("MIZ identity 180 x1 nt=2000 from zero", lambda: miz_case(pkg, co, cl, "identity", 180, 1, 2000, 0, (1, 10, 50))),
         ("MIZ sin 1000 x5 nt=60000 spin 20", lambda: miz_case(pkg, co, cl, "sin", 1000, 5, 60000, 20, (1, 20))),
         ("MIZ identity 1024 x8 nt=262144 spin 50", lambda: miz_case(pkg, co, cl, "identity", 1024, 8, 262144, 50, (1, 20))),
