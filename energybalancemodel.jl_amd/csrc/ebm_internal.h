@@ -119,6 +119,9 @@ hipError_t launch_divide(const double *a, const double *b, double *q, int n, hip
 // out[col] = hemispheric_mean(field[col], x), src/utilities.jl:397-403 (sequential sum, bit-exact)
 hipError_t launch_hemispheric_mean(const double *field, const double *x, int pitch, int nlat, int ncol, double *out,
                                    hipStream_t s);
+// out = base + D d/dx[(1-x^2) d temp/dx] per column ([ncol][pitch] device arrays; base may be null)
+hipError_t launch_diffusion(const double *temp, const double *base, double *out, const double *geom, long long gstride,
+                            const Params *p, int grid_kind, int pitch, int nlat, int ncol, hipStream_t s);
 // annual_mean (src/infrastructure.jl:536-544): dst[col][k] = sum/nt with `sum` in the pair-split
 // layout of the step kernels, then sum = 0
 hipError_t launch_finish_mean(double *dst, double *sum, double nt, int ncol, const LaunchCfg &cfg, hipStream_t s);

@@ -1081,6 +1081,40 @@ __global__ void hemispheric_mean_kernel(const double *__restrict__ field, const 
         out[blockIdx.x] = acc;
     }
 }
+// The diffusion operator on its own: out = base + D d/dx[(1-x^2) d temp/dx], one thread per cell —
+// diffusion!(base, temp, st, par) / diffusion(T, st, par), src/infrastructure.jl:495-533, with the
+// same device functions (and hence the same bits) the step kernels use inside their fused physics.
+template <int GRID>
+__global__ void diffusion_kernel(const double *__restrict__ temp, const double *__restrict__ base,
+                                 double *__restrict__ out, const double *__restrict__ geom, long long gstride,
+                                 const Params *__restrict__ pp, int pitch, int nlat) {
+    const int col = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nlat) return;
+    const double *T = temp + (size_t)col * pitch;
+    const double tk = T[k], tm = k > 0 ? T[k - 1] : 0.0, tp = k < nlat - 1 ? T[k + 1] : 0.0;
+    double term;
+    if (GRID == 0) {
+        term = diffusion_uniform(k, nlat, geom[G_LO * gstride + k], geom[G_DI * gstride + k], geom[G_UP * gstride + k],
+                                 tm, tk, tp);
+    } else {
+        const double *x = geom + G_X * gstride;
+        const double xk = x[k], xm = k > 0 ? x[k - 1] : 0.0, xp = k < nlat - 1 ? x[k + 1] : 0.0;
+        double xxl, xxr;
+        const double Fl = interface_flux(k, nlat, xm, xk, tm, tk, xxl);
+        const double Fr = interface_flux(k + 1, nlat, xk, xp, tk, tp, xxr);
+        term = ieee_div(pp->D * (Fr - Fl), xxr - xxl);                  // :524
+    }
+    out[(size_t)col * pitch + k] = (base ? base[(size_t)col * pitch + k] : 0.0) + term;
+}
+hipError_t launch_diffusion(const double *temp, const double *base, double *out, const double *geom, long long gstride,
+                            const Params *p, int grid_kind, int pitch, int nlat, int ncol, hipStream_t s) {
+    dim3 grid((nlat + 255) / 256, ncol), block(256);
+    if (grid_kind == 0) diffusion_kernel<0><<<grid, block, 0, s>>>(temp, base, out, geom, gstride, p, pitch, nlat);
+    else diffusion_kernel<1><<<grid, block, 0, s>>>(temp, base, out, geom, gstride, p, pitch, nlat);
+    return hipGetLastError();
+}
+
 // annual_mean (src/infrastructure.jl:536-544, crossmean src/utilities.jl:390-395): sum / nt, from
 // the pair-split layout of save_pair to the natural [col][pitch] one; the sum restarts at zero.
 __global__ void finish_mean_kernel(double *__restrict__ dst, double *__restrict__ sum, double nt, int threads,

@@ -459,6 +459,33 @@ int ebm_get_field_device(ebm_handle_t h, int field, double *dev_out) {
     return EBM_OK;
 }
 
+int ebm_diffusion(ebm_handle_t h, const double *temp, const double *base, double *out) {
+    if (!h || !temp || !out) return fail(EBM_ERR_ARG, "ebm_diffusion: null argument");
+    if (h->model != EBM_MODEL_MIZ)
+        return fail(EBM_ERR_ARG, "ebm_diffusion: needs a MIZ handle (the classic model carries get_diffop unscaled inside kappa, src/classic.jl:21)");
+    HIPCHK(hipSetDevice(h->device));
+    const size_t npitch = (size_t)h->ncol * h->pitch;
+    double *buf = nullptr;                               // temp | base | out, [ncol][pitch] each
+    HIPCHK(hipMalloc(&buf, sizeof(double) * npitch * 3));
+    hipError_t e = hipMemsetAsync(buf, 0, sizeof(double) * npitch * 3, h->stream);
+    auto up = [&](double *dst, const double *src) {
+        return hipMemcpy2DAsync(dst, sizeof(double) * h->pitch, src, sizeof(double) * h->nlat, sizeof(double) * h->nlat,
+                                h->ncol, hipMemcpyHostToDevice, h->stream);
+    };
+    if (e == hipSuccess) e = up(buf, temp);
+    if (e == hipSuccess && base) e = up(buf + npitch, base);
+    if (e == hipSuccess)
+        e = ebm::launch_diffusion(buf, base ? buf + npitch : nullptr, buf + 2 * npitch, h->geom, h->gstride, h->p_dev,
+                                  h->grid, (int)h->pitch, h->nlat, h->ncol, h->stream);
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(out, sizeof(double) * h->nlat, buf + 2 * npitch, sizeof(double) * h->pitch,
+                             sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("ebm_diffusion: ") + hipGetErrorString(e));
+    return EBM_OK;
+}
+
 int ebm_field_device_ptr(ebm_handle_t h, int field, double **dptr, long long *pitch) {
     if (!h || !dptr) return fail(EBM_ERR_ARG, "ebm_field_device_ptr: null argument");
     if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_field_device_ptr: field not part of this model");

@@ -119,6 +119,15 @@ class Engine:
         check(self.lib.ebm_get_field_device(self._h, FIELD[name], C.c_void_p(dev_ptr)),
               "ebm_get_field_device")
 
+    def diffusion(self, temp, base=None) -> np.ndarray:
+        """``diffusion!(base, temp, st, par)`` / ``diffusion(T, st, par)`` (reference
+        src/infrastructure.jl:495-533) per column on the device: base + D d/dx[(1-x^2) d temp/dx]."""
+        t = as_f64(temp).reshape(self.ncol, self.nlat)
+        b = None if base is None else as_f64(base).reshape(self.ncol, self.nlat)
+        out = np.empty((self.ncol, self.nlat))
+        check(self.lib.ebm_diffusion(self._h, dptr(t), dptr(b), dptr(out)), "ebm_diffusion")
+        return out
+
     def field_device_ptr(self, name: str):
         p, pitch = C.c_void_p(), C.c_longlong()
         check(self.lib.ebm_field_device_ptr(self._h, FIELD[name], C.byref(p), C.byref(pitch)),

@@ -102,6 +102,13 @@ int ebm_hemispheric_mean(ebm_handle_t h, int field, double *out);
  * RCCL gather): dev_out[ncol] / dev_out[ncol][nlat] packed, on the handle's device.  Synchronous. */
 int ebm_hemispheric_mean_device(ebm_handle_t h, int field, double *dev_out);
 int ebm_get_field_device(ebm_handle_t h, int field, double *dev_out);
+/* The meridional diffusion operator on its own — diffusion!(base, temp, st, par) / diffusion(T, st, par)
+ * = D∇², src/infrastructure.jl:495-533: out = base + D d/dx[(1-x^2) d temp/dx] per column, with the
+ * handle's grid kind (identity: the CSC product of par.D*get_diffop, :495-497; any other grid: the flux
+ * form, :505-526) and the very device functions the step kernels fuse — bit for bit the reference's
+ * operation order.  temp, base (NULL = zeros), out: [ncol][nlat] host arrays.  MIZ handles only.
+ * Synchronous. */
+int ebm_diffusion(ebm_handle_t h, const double *temp, const double *base, double *out);
 /* Device pointer of a field and its row pitch in elements (>= nlat), for zero-copy users
  * (e.g. a torch tensor view).  The pointer stays valid until ebm_destroy. */
 int ebm_field_device_ptr(ebm_handle_t h, int field, double **dptr, long long *pitch);

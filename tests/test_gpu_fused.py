@@ -280,3 +280,39 @@ def test_device_pointer_entry_points(pkg):
     # single-process gather is the identity, tensor or array
     assert np.array_equal(pkg.gather_columns(run.hemispheric_mean_tensor("T"), ncol), eng.hemispheric_mean("T"))
     run.close()
+
+
+# ---- the diffusion operator on its own ---------------------------------------------
+@pytest.mark.parametrize("kind", ["identity", "sin"])
+@pytest.mark.parametrize("nlat", [2, 63, 180, 1000, 4096])
+def test_diffusion_operator_is_bit_exact(pkg, oracle, kind, nlat):
+    """ebm_diffusion = diffusion!(base, temp, st, par) / diffusion(T, st, par), src/infrastructure.jl:495-533,
+    evaluated by the device functions the step kernels fuse: bit for bit the oracle's restatement of the
+    reference's operation order (CSC product on the identity grid, flux form elsewhere), zero-flux ends,
+    NaN / Inf cells included, with and without a base."""
+    rng = np.random.default_rng(nlat)
+    st = pkg.SpaceTime(kind, nlat, 2000, 1)
+    par = pkg.default_parameters("MIZ")
+    ncol = 3
+    temp = rng.normal(0.0, 15.0, (ncol, nlat))
+    temp[1] = 30.0 - 45.0 * st.x ** 2                          # a smooth profile
+    if nlat > 10:
+        temp[2, 5] = np.nan
+        temp[2, nlat - 2] = np.inf
+    base = rng.normal(0.0, 3.0, (ncol, nlat))
+    geom = oracle.DiffusionGeometry(kind if kind == "identity" else "sin", st.x, par["D"])
+    with make_engine(pkg, "MIZ", st, par, ncol) as eng:
+        got0 = eng.diffusion(temp)
+        got1 = eng.diffusion(temp, base)
+    with np.errstate(all="ignore"):
+        for c in range(ncol):
+            assert np.array_equal(got0[c], geom.add(np.zeros(nlat), temp[c]), equal_nan=True), (c, "no base")
+            assert np.array_equal(got1[c], geom.add(base[c], temp[c]), equal_nan=True), (c, "base")
+    # a constant has no gradient: exactly zero in the flux form, zero to rounding in the matrix form
+    with make_engine(pkg, "MIZ", st, par, 1) as eng:
+        const = eng.diffusion(np.full((1, nlat), 7.25))
+        assert np.all(const == 0.0) if kind == "sin" else np.all(np.abs(const) <= 1e-9 * 7.25 * par["D"] * nlat ** 2)
+    st2 = pkg.SpaceTime(kind, nlat, 2000, 1)
+    with make_engine(pkg, "Classic", st2, pkg.default_parameters("Classic"), 1) as eng:
+        with pytest.raises(pkg.EBMError, match="MIZ handle"):
+            eng.diffusion(np.zeros((1, nlat)))
