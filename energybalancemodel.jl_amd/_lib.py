@@ -50,6 +50,14 @@ def load():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C csrc); "
             "this package has no CPU fallback")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 and the system has another.  If this
+    # library pulls in the system's first, a later `import torch` finds a runtime it did not expect
+    # ("No HIP GPUs are available").  Importing torch first makes the dynamic loader resolve this
+    # library's libamdhip64 dependency to the copy torch has already loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.ebm_last_error.restype = C.c_char_p
     lib.ebm_version.restype = C.c_char_p
