@@ -30,7 +30,15 @@ namespace ebm {
 // Outputs are streamed: written once per step and not read again before the next launch.  With
 // the non-temporal policy they do not allocate in L2 and drain faster (0.238 -> 0.217 ms per step on
 // the 4096 x 2048 workload; the same policy on the loads was slower and is not used).
-#ifndef EBM_PLAIN_STORES
+#if defined(EBM_TIMING_NO_STORES)
+// Timing-only A/B build (never shipped, results are garbage): the streamed output stores are dropped, what
+// remains is loads + arithmetic — the ceiling a design that hid every store would reach.  The values
+// are kept alive so that the arithmetic is not eliminated.
+#define EBM_STORE2(ptr, v)                                                            \
+    do {                                                                              \
+        asm volatile("" ::"v"((v).x), "v"((v).y), "s"(ptr));                          \
+    } while (0)
+#elif !defined(EBM_PLAIN_STORES)
 typedef double ebm_dvec2 __attribute__((ext_vector_type(2)));
 #define EBM_STORE2(ptr, v)                                                            \
     do {                                                                              \
