@@ -9,7 +9,9 @@ import math
 import numpy as np
 import pytest
 
-from conftest import load_golden, scaled_err
+import os
+
+from conftest import ROOT, load_golden, scaled_err
 
 PROG = ("Ei", "Ew", "h", "D", "phi")
 DIAG = ("Tw", "Ti", "n", "E", "T")
@@ -257,3 +259,62 @@ def test_classic_c_port_equals_numpy_on_random_states(oracle, coracle, seed):
     out = coracle.classic_run(st.x, par, st.dt, np.array([ct_i]), np.array([ct_n]), np.array([f]), None, state)
     for k, got in (("E", state["E"][0]), ("Tg", state["Tg"][0]), ("T", out["T"][0]), ("h", out["h"][0])):
         assert np.array_equal(got, new[k], equal_nan=True), k
+
+
+def test_c_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """The checker itself, built with -fsanitize=address,undefined (CPU only; GPU sanitizers are not
+    available on this pool): a MIZ run on both grids, a ragged multi-column case and a classic run must
+    finish without a sanitizer report."""
+    import subprocess
+    import textwrap
+    src = os.path.join(ROOT, "oracle", "ebm_oracle.c")
+    exe = tmp_path / "oracle_asan"
+    main = tmp_path / "main.c"
+    main.write_text(textwrap.dedent("""
+        #include <stdio.h>
+        #include <stdlib.h>
+        #include <math.h>
+        int ebmo_miz_run(int, int, int, const double *, const double *, double, int, const double *, const double *,
+                         const double *, double *, double *, double *, double *, double *, double *, double *, double *,
+                         double *, double *, double *, long long *, int);
+        int ebmo_classic_run(int, int, const double *, const double *, double, int, const double *, const double *,
+                             const double *, const double *, double *, double *, double *, double *, int);
+        static const double par[25] = {0.6, 193.0, 2.1, 9.8, 420.0, 338.0, 240.0, 0.7, 0.1, 0.4, 4.0, 2.0, 9.5, 0.0, 0.098,
+                                       1e-5, 0.0, 50.4576, 1.36, 0.66, 0.5, 1.0, 156.0, 0.1, 315360.0};
+        int main(void) {
+            for (int kind = 0; kind < 2; ++kind) {
+                const int nx = 61, ncol = 3, nsteps = 40;
+                double *x = malloc(sizeof(double) * nx), *ct = malloc(sizeof(double) * nsteps), *ft = calloc(nsteps, sizeof(double));
+                double fcol[3] = {-1.0, 0.0, 2.0};
+                for (int k = 0; k < nx; ++k) x[k] = kind ? sin((k + 0.5) * M_PI / 2.0 / nx) : (k + 0.5) / nx;
+                for (int s = 0; s < nsteps; ++s) ct[s] = cos(2.0 * M_PI * (s + 0.5) / 2000.0);
+                double *f[11];
+                for (int i = 0; i < 11; ++i) f[i] = calloc((size_t)nx * ncol, sizeof(double));
+                long long cnt[2] = {0, 0};
+                ebmo_miz_run(kind, nx, ncol, x, par, 1.0 / 2000.0, nsteps, ct, ft, fcol, f[0], f[1], f[2], f[3], f[4], f[5],
+                             f[6], f[7], f[8], f[9], f[10], cnt, 1);
+                printf("miz kind %d: solves %lld\\n", kind, cnt[0]);
+                for (int i = 0; i < 11; ++i) free(f[i]);
+                free(x); free(ct); free(ft);
+            }
+            {
+                const int nx = 37, ncol = 2, nsteps = 25;
+                double *x = malloc(sizeof(double) * nx), *c0 = malloc(sizeof(double) * nsteps), *c1 = malloc(sizeof(double) * nsteps);
+                double *ft = calloc(nsteps, sizeof(double)), *E = malloc(sizeof(double) * nx * ncol), *Tg = malloc(sizeof(double) * nx * ncol);
+                double *T = malloc(sizeof(double) * nx * ncol), *h = malloc(sizeof(double) * nx * ncol);
+                for (int k = 0; k < nx; ++k) x[k] = (k + 0.5) / nx;
+                for (int s = 0; s < nsteps; ++s) { c0[s] = cos(2.0 * M_PI * (s + 0.5) / 2000.0); c1[s] = cos(2.0 * M_PI * (s + 1.5) / 2000.0); }
+                for (int i = 0; i < nx * ncol; ++i) { double ts = 30.0 - 45.0 * x[i % nx] * x[i % nx]; Tg[i] = ts; E[i] = ts >= 0 ? 9.8 * ts : 9.5 * ts / 7.5; }
+                ebmo_classic_run(nx, ncol, x, par, 1.0 / 2000.0, nsteps, c0, c1, ft, NULL, E, Tg, T, h, 1);
+                printf("classic: E[0] %.6f\\n", E[0]);
+                free(x); free(c0); free(c1); free(ft); free(E); free(Tg); free(T); free(h);
+            }
+            return 0;
+        }
+    """))
+    subprocess.check_call(["gcc", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", "-ffp-contract=off", "-o", str(exe), str(main), src, "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-3000:]
+    assert "miz kind 1" in out.stdout and "classic" in out.stdout
