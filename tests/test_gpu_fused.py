@@ -172,6 +172,7 @@ def sequential_mean(raw, nt):
     ("MIZ", "sin", 180, 2, 400, 2),
     ("MIZ", "identity", 255, 3, 600, 1),          # ragged: padding cells of sums and snapshots
     ("MIZ", "sin", 1024, 2, 70000, 1),            # 256 threads; only the first 300 steps of the year are run
+    ("MIZ", "sin", 1024, 48, 70000, 1),           # 3.9 MB per snapshot: the 256 MiB staging ring is flushed 5 times
     ("Classic", "identity", 180, 2, 400, 2),
     ("Classic", "identity", 333, 1, 500, 1),
 ])
