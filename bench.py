@@ -103,6 +103,10 @@ def cpu_baseline(pkg, wl, st, par, state, fcol, first_step, budget_s):
     }
 
 
+def cells_bytes(nlat, ncol):
+    return 8.0 * nlat * ncol
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,8 +239,23 @@ def main():
     # ---- after the timed region: diagnostics of the state that was timed, CPU baseline --------------
     cpu = None
     ice_fraction = None
+    host_transfer = None
     if model == "MIZ":
+        t0 = time.perf_counter()
         state = {k: eng.get_field(k) for k in ("Ei", "Ew", "h", "D", "phi", "T0")}
+        dl = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for k in ("Ei", "Ew", "h", "D", "phi"):
+            eng.set_field(k, state[k])                       # the same values back: the state is unchanged
+        ul = time.perf_counter() - t0
+        # what crossing the C ABI with HOST buffers costs (ebm_get_field / ebm_set_field, pageable memory):
+        # never part of `value`, which is measured with the state resident in HBM
+        host_transfer = {"download_GBps": 6 * cells_bytes(nlat, ncol) / dl / 1e9,
+                         "upload_GBps": 5 * cells_bytes(nlat, ncol) / ul / 1e9,
+                         "state_round_trip_ms": (dl * 5 / 6 + ul) * 1e3,
+                         "note": "5 prognostic fields down + up through ebm_get_field/ebm_set_field; "
+                                 "state_round_trip_ms / ms_per_step = steps a resident state must take per round trip "
+                                 "for PCIe to cost as much as the stepping"}
         ice_fraction = float(np.mean(state["phi"] > 0))
         if rank == 0 and world == 1 and args.cpu_budget > 0:
             cpu = cpu_baseline(pkg, wl, st, par, state, fcol, clock["step"], args.cpu_budget)
@@ -308,6 +327,7 @@ def main():
             "frac_traffic": (traffic / launch_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
         },
         "cpu_baseline": cpu,
+        "host_transfer": host_transfer,
     }
     if rank == 0:
         print(json.dumps(out))
