@@ -21,6 +21,7 @@ def pytest_configure(config):
 # a process is refused).  So the launcher is started here, at session start, whenever GPU tests are
 # selected and a device is present; tests/test_gpu_configs.py waits for it and checks its output.
 TWO_RANK = {"proc": None, "out": None, "log": None}
+C_EXAMPLE = {"proc": None, "out": None, "err": None}      # examples/c_abi_example.c, same reason
 
 
 def pytest_sessionstart(session):
@@ -39,6 +40,17 @@ def pytest_sessionstart(session):
     TWO_RANK["out"] = os.path.join(tmp, "gathered.npz")
     TWO_RANK["log"] = os.path.join(tmp, "two_rank.log")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # the plain-C caller of the ABI: build with gcc, run as a child (tests/test_gpu_configs.py checks it)
+    exe = os.path.join(tmp, "c_abi_example")
+    libdir = os.path.join(ROOT, "energybalancemodel.jl_amd")
+    build = subprocess.run(
+        ["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_example.c"),
+         "-o", exe, "-L", libdir, "-lebm_hip", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+         "-Wl,-rpath-link,/opt/rocm/lib"], capture_output=True, text=True)
+    C_EXAMPLE["err"] = build.stderr
+    if build.returncode == 0:
+        C_EXAMPLE["out"] = os.path.join(tmp, "c_abi_example.out")
+        C_EXAMPLE["proc"] = subprocess.Popen([exe], stdout=open(C_EXAMPLE["out"], "w"), stderr=subprocess.STDOUT)
     with open(TWO_RANK["log"], "w") as log:
         TWO_RANK["proc"] = subprocess.Popen(
             [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",

@@ -138,3 +138,36 @@ def test_two_process_sharded_engine(pkg):
     assert np.array_equal(got["hmT"], hmT.cpu().numpy(), equal_nan=True)
     assert np.array_equal(got["hmphi"], hmphi.cpu().numpy(), equal_nan=True)
     assert got["T"].shape == (ncol, worker.NLAT) and len(np.unique(got["hmT"])) == worker.NMEMBER
+
+
+def test_plain_c_caller_of_the_abi(pkg):
+    """examples/c_abi_example.c — gcc -std=c99 against include/ebm_hip.h, linked to libebm_hip.so, run as its
+    own process (built and started by conftest.py at session start): ten steps of the reference test's
+    configuration through ebm_step + ebm_run.  Its printed T and phi equal, bit for bit, the same calls made
+    through the Python mirror's ctypes binding — the boundary is the C ABI, not the binding."""
+    import math
+    info = conftest.C_EXAMPLE
+    if info["proc"] is None:
+        if info["err"]:
+            pytest.fail("gcc could not build examples/c_abi_example.c:\n" + info["err"][-2000:])
+        pytest.skip("the C example was not started (no GPU at session start)")
+    rc = info["proc"].wait(timeout=300)
+    text = open(info["out"]).read()
+    assert rc == 0, text[-2000:]
+    assert "steps 10 solves" in text and "launches 10" in text
+    vals = np.array([[float(line.split()[1]), float(line.split()[3])] for line in text.splitlines() if line.startswith("T[")])
+    assert vals.shape == (180, 2)
+    nx, nt = 180, 2000
+    du = (math.pi / 2.0) / nx
+    x = np.array([math.sin(du / 2.0 + k * du) for k in range(nx)])
+    ctab = [math.cos(2.0 * math.pi * ((2.0 * i + 1.0) / (2.0 * nt))) for i in range(nt)]
+    par = pkg.default_parameters("MIZ")
+    with pkg.Engine("MIZ", "nonuniform", x, pkg.engine.param_vector(par, pkg.default_parval), 1.0 / nt, 1, device=0) as eng:
+        for i in range(5):
+            eng.step(ctab[i], 0.0, 0.0, True)
+        eng.set_time_table([(2.0 * i + 1.0) / (2.0 * nt) for i in range(nt)])      # cos(2.0*pi*t) of the same t
+        assert np.array_equal(eng.ttab, np.array(ctab))
+        eng.run(5, 5, None, True)
+        T, phi = eng.get_field("T")[0], eng.get_field("phi")[0]
+    assert np.array_equal(vals[:, 0], T, equal_nan=True) and np.array_equal(vals[:, 1], phi, equal_nan=True)
+    assert np.any(phi > 0)

@@ -186,3 +186,15 @@ def test_schedule_words_follow_the_forcing_domain(pkg):
         for T in list(np.linspace(0.0, 60.0, 481)) + [float(d) for d in f.domain]:
             assert device_eval(w, T) == f(T), (repr(f), T)
     assert words(pkg.Forcing(0.0, 5.0, -5.0, (10, 10), (0.5, -0.5)))[5:] == [10.0, 20.0, 30.0, 50.0]
+
+
+def test_header_is_valid_c99(tmp_path):
+    """include/ebm_hip.h is a C header (no C++, no torch types): it must compile as strict C99, and a
+    plain-C caller (examples/c_abi_example.c) must compile against it."""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    src = tmp_path / "t.c"
+    src.write_text('#include "ebm_hip.h"\nint main(void) { return (int)sizeof(ebm_handle_t) * 0 + EBM_OK; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, "-c",
+                           os.path.join(ROOT, "examples", "c_abi_example.c"), "-o", str(tmp_path / "ex.o")])
