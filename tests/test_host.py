@@ -198,3 +198,98 @@ def test_header_is_valid_c99(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", inc, "-c",
                            os.path.join(ROOT, "examples", "c_abi_example.c"), "-o", str(tmp_path / "ex.o")])
+
+
+# ---- the reviewed-only Julia shim, machine-checked against the header ------------------------------
+_C2J = {  # C parameter type (normalised) -> the Julia ccall argument types that bind it
+    "ebm_handle_t*": {"Ref{Ptr{Cvoid}}"}, "ebm_handle_t": {"Ptr{Cvoid}"}, "int": {"Cint"}, "double": {"Cdouble"},
+    "const double*": {"Ptr{Cdouble}"}, "double*": {"Ptr{Cdouble}"}, "const int*": {"Ptr{Cint}"},
+    "int*": {"Ptr{Cint}"}, "long long*": {"Ptr{Clonglong}"}, "long long": {"Clonglong"},
+    "float*": {"Ptr{Cfloat}", "Ref{Cfloat}"}, "double**": {"Ptr{Ptr{Cdouble}}", "Ref{Ptr{Cdouble}}"},
+}
+
+
+def _header_prototypes():
+    hdr = open(os.path.join(ROOT, "include", "ebm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r"\b(int|const char \*)\s*(ebm_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr):
+        params = []
+        for a in (p.strip() for p in args.split(",")):
+            if a in ("void", ""):
+                continue
+            a = re.sub(r"\s+", " ", a)
+            m = re.match(r"(.*?)(\**)\s*([A-Za-z_][A-Za-z0-9_]*)$", a)          # type, stars, name
+            params.append((m.group(1).strip() + m.group(2)).replace(" *", "*"))
+        protos[name] = (ret.replace(" ", ""), params)
+    return protos
+
+
+def _split_top(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        elif ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _julia_ccalls():
+    src = open(os.path.join(ROOT, "julia", "EBMHip.jl")).read()
+    src = re.sub(r"#=.*?=#", "", src, flags=re.S)
+    src = "\n".join(line.split("#")[0] if not line.lstrip().startswith("#") else "" for line in src.splitlines())
+    calls = []
+    for m in re.finditer(r"ccall\(\(:(ebm_[a-z0-9_]+), libebm\),", src):
+        i = m.end()
+        depth, j = 1, i                                    # find the matching ')' of ccall(
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[j], 0)
+            j += 1
+        parts = _split_top(src[i:j - 1])
+        ret, types = parts[0], _split_top(parts[1].strip()[1:-1])
+        calls.append((m.group(1), ret, [t for t in types if t], parts[2:]))
+    return calls
+
+
+def test_julia_shim_ccalls_match_the_header():
+    """julia/EBMHip.jl cannot be executed here (no Julia), but its ccalls can be read: every one must name
+    a function the header declares, with the header's return type, the header's number of parameters, a
+    Julia type that binds each C parameter type, and exactly as many arguments as parameter types."""
+    protos = _header_prototypes()
+    assert "ebm_integrate" in protos and len(protos["ebm_integrate"][1]) == 13
+    calls = _julia_ccalls()
+    assert {c[0] for c in calls} >= {"ebm_create", "ebm_destroy", "ebm_set_field", "ebm_get_field", "ebm_step",
+                                    "ebm_set_time_table", "ebm_integrate", "ebm_get_counters", "ebm_last_error",
+                                    "ebm_set_column_schedule"}
+    for name, ret, types, args in calls:
+        assert name in protos, f"{name} is not declared in include/ebm_hip.h"
+        cret, cparams = protos[name]
+        assert ret == ("Cstring" if cret == "constchar*" else "Cint"), (name, ret)
+        assert len(types) == len(cparams), f"{name}: {len(types)} Julia types for {len(cparams)} C parameters"
+        assert len(args) == len(types), f"{name}: {len(args)} arguments for {len(types)} parameter types"
+        for jt, ct in zip(types, cparams):
+            assert jt in _C2J[ct], f"{name}: Julia {jt} does not bind C {ct}"
+
+
+def test_julia_shim_enums_match_the_header():
+    """PARAM_ORDER, FIELD and MODEL of the shim against enum ebm_param / ebm_field / ebm_model."""
+    hdr = open(os.path.join(ROOT, "include", "ebm_hip.h")).read()
+    jl = open(os.path.join(ROOT, "julia", "EBMHip.jl")).read()
+    params = re.findall(r"EBM_P_([A-Za-z0-9]+)", re.search(r"enum ebm_param \{(.*?)\};", hdr, flags=re.S).group(1))
+    params = [p for p in params if p != "COUNT"]
+    jl_params = re.findall(r":([A-Za-z0-9]+)", re.search(r"const PARAM_ORDER = \((.*?)\)", jl, flags=re.S).group(1))
+    assert jl_params == params
+    fields = [f for f in re.findall(r"EBM_F_([A-Za-z0-9]+)", re.search(r"enum ebm_field \{(.*?)\};", hdr, flags=re.S).group(1))
+              if f != "COUNT"]
+    jl_fields = dict((k, int(v)) for k, v in re.findall(r":([A-Za-z0-9]+) => (\d+)", re.search(r"const FIELD = Dict\((.*?)\)\n", jl, flags=re.S).group(1)))
+    assert jl_fields == {f: i for i, f in enumerate(fields)}
+    assert re.search(r"const MODEL = Dict\(:MIZ => 0, :Classic => 1\)", jl)
+    assert "EBM_MODEL_MIZ = 0, EBM_MODEL_CLASSIC = 1" in hdr
