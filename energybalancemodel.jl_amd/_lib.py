@@ -27,7 +27,7 @@ EXPORTS = (
     "ebm_get_field", "ebm_hemispheric_mean", "ebm_hemispheric_mean_device", "ebm_get_field_device",
     "ebm_field_device_ptr", "ebm_diffusion", "ebm_set_column_forcing", "ebm_set_column_schedule",
     "ebm_set_step_clock", "ebm_set_time_table",
-    "ebm_step", "ebm_run", "ebm_run_fused", "ebm_integrate", "ebm_sync", "ebm_get_counters",
+    "ebm_step", "ebm_run", "ebm_run_fused", "ebm_integrate", "ebm_integrate_hemispheric", "ebm_sync", "ebm_get_counters",
     "ebm_reset_counters", "ebm_timer_start", "ebm_timer_stop", "ebm_launch_info",
     "ebm_selftest_divide",
 )
@@ -81,6 +81,8 @@ def load():
     lib.ebm_run_fused.argtypes = [C.c_void_p, C.c_longlong, C.c_int, _dp, C.c_int, C.c_int]
     lib.ebm_integrate.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_int, C.c_int,
                                   C.c_int, C.POINTER(C.c_int), _dp, _dp, _dp, _dp]
+    lib.ebm_integrate_hemispheric.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int, C.c_int, C.c_int,
+                                              C.POINTER(C.c_int), _dp, _dp, _dp]
     lib.ebm_sync.argtypes = [C.c_void_p]
     lib.ebm_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     lib.ebm_reset_counters.argtypes = [C.c_void_p]

@@ -630,11 +630,15 @@ int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double
     return EBM_OK;
 }
 
-int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int lastonly,
-                  int winter_inx, int summer_inx, int nvars, const int *fields, double *raw,
-                  double *winter, double *summer, double *avg) {
+// integrate + savesol! (ebm_integrate) with, optionally, the per-column hemispheric means of the seasonal
+// outputs reduced on the device (ebm_integrate_hemispheric): hm_* are [nvars][dur][ncol] host arrays.
+static int integrate_impl(ebm_handle_t h, int nt, int dur, const double *f_steps, int lastonly,
+                          int winter_inx, int summer_inx, int nvars, const int *fields, double *raw,
+                          double *winter, double *summer, double *avg, double *hm_winter, double *hm_summer,
+                          double *hm_avg) {
     if (!h || nt < 1 || dur < 1 || nvars < 0 || nvars > ebm::kMaxQuantities || (nvars > 0 && !fields))
         return fail(EBM_ERR_ARG, "ebm_integrate: bad argument");
+    if ((hm_winter || hm_summer || hm_avg) && nvars < 1) return fail(EBM_ERR_ARG, "ebm_integrate_hemispheric: no variables");
     if ((long long)h->ttab.size() != nt) return fail(EBM_ERR_ARG, "ebm_integrate: time table length must equal nt");
     SaveTarget save;
     std::memset(save.var_of, -1, sizeof(save.var_of));
@@ -652,11 +656,12 @@ int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int la
     // Device buffers: raw snapshots are staged as [var][chunk][ncol][pitch] and flushed to the host
     // when the chunk is full; the annual-mean sums are [var][ncol*pitch] (pair-split layout).
     long long chunk = 0;
-    double *stage = nullptr, *sums = nullptr, *mean = nullptr;
+    double *stage = nullptr, *sums = nullptr, *mean = nullptr, *hm = nullptr;
     auto cleanup = [&]() {
         if (stage) (void)hipFree(stage);
         if (sums) (void)hipFree(sums);
         if (mean) (void)hipFree(mean);
+        if (hm) (void)hipFree(hm);
     };
 #define EBM_TRY(expr)                                                                     \
     do {                                                                                  \
@@ -672,7 +677,23 @@ int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int la
         if (chunk > nraw) chunk = nraw;
         EBM_TRY(hipMalloc(&stage, sizeof(double) * npitch * (size_t)nvars * (size_t)chunk));
     }
-    if (avg && nvars > 0) {
+    if ((hm_winter || hm_summer || hm_avg) && nvars > 0)
+        EBM_TRY(hipMalloc(&hm, sizeof(double) * (size_t)h->ncol * (size_t)nvars));
+    // hemispheric_mean (src/utilities.jl:397-403) of every saved variable of a padded device field set,
+    // reduced on the device, [nvars][ncol] -> out[v][year][col]
+    auto means_to_host = [&](double *out, long long year, auto field_of) -> hipError_t {
+        for (int v = 0; v < nvars; ++v) {
+            hipError_t e = ebm::launch_hemispheric_mean(field_of(v), h->geom + (size_t)ebm::G_X * h->gstride, (int)h->pitch,
+                                                        h->nlat, h->ncol, hm + (size_t)v * h->ncol, h->stream);
+            if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipStreamSynchronize(h->stream);
+        for (int v = 0; v < nvars && e == hipSuccess; ++v)
+            e = hipMemcpy(out + ((size_t)v * dur + (size_t)(year - 1)) * h->ncol, hm + (size_t)v * h->ncol,
+                          sizeof(double) * (size_t)h->ncol, hipMemcpyDeviceToHost);
+        return e;
+    };
+    if ((avg || hm_avg) && nvars > 0) {
         EBM_TRY(hipMalloc(&sums, sizeof(double) * npitch * (size_t)nvars));
         EBM_TRY(hipMemsetAsync(sums, 0, sizeof(double) * npitch * (size_t)nvars, h->stream));
         EBM_TRY(hipMalloc(&mean, sizeof(double) * npitch));
@@ -708,26 +729,36 @@ int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int la
         // sums on every step, the raw snapshot on the steps that are kept; the diagnostic FIELDS are
         // only stored on steps whose snapshot is copied out of them (seasons) and on the last one
         const bool want_raw = stage && (!lastonly || tinx > total - nt);
-        const bool want_season = (ti == winter_inx && winter) || (ti == summer_inx && summer);
+        const bool want_season = (ti == winter_inx && (winter || hm_winter)) || (ti == summer_inx && (summer || hm_summer));
         const int diag = (want_season || tinx == total) ? 1 : 0;
         save.stage = want_raw ? stage : nullptr;
         save.stage_offset = staged * (long long)npitch;
         int rc = do_step(h, h->ttab[ti - 1], h->ttab[ti % nt], f, diag, tinx - 1, (sums || want_raw) ? &save : nullptr);
         if (rc) { cleanup(); return rc; }
         if (want_raw && ++staged == chunk) EBM_TRY(flush());
+        auto state_field = [&](int v) { return (const double *)h->field[fields[v]]; };
         if (ti == winter_inx) {
             if (winter)
                 for (int v = 0; v < nvars; ++v)
                     EBM_TRY(snapshot_to_host(winter + ((size_t)v * dur + (year - 1)) * ncell, h->field[fields[v]]));
+            if (hm_winter) EBM_TRY(means_to_host(hm_winter, year, state_field));
         } else if (ti == summer_inx) {
             if (summer)
                 for (int v = 0; v < nvars; ++v)
                     EBM_TRY(snapshot_to_host(summer + ((size_t)v * dur + (year - 1)) * ncell, h->field[fields[v]]));
+            if (hm_summer) EBM_TRY(means_to_host(hm_summer, year, state_field));
         } else if (ti == nt) {
             if (sums)
                 for (int v = 0; v < nvars; ++v) {
                     EBM_TRY(ebm::launch_finish_mean(mean, sums + (size_t)v * npitch, (double)nt, h->ncol, h->cfg, h->stream));
-                    EBM_TRY(snapshot_to_host(avg + ((size_t)v * dur + (year - 1)) * ncell, mean));
+                    if (avg) EBM_TRY(snapshot_to_host(avg + ((size_t)v * dur + (year - 1)) * ncell, mean));
+                    if (hm_avg) {
+                        EBM_TRY(ebm::launch_hemispheric_mean(mean, h->geom + (size_t)ebm::G_X * h->gstride, (int)h->pitch,
+                                                             h->nlat, h->ncol, hm + (size_t)v * h->ncol, h->stream));
+                        EBM_TRY(hipStreamSynchronize(h->stream));
+                        EBM_TRY(hipMemcpy(hm_avg + ((size_t)v * dur + (size_t)(year - 1)) * h->ncol, hm + (size_t)v * h->ncol,
+                                          sizeof(double) * (size_t)h->ncol, hipMemcpyDeviceToHost));
+                    }
                     EBM_TRY(hipStreamSynchronize(h->stream));
                 }
         }
@@ -739,6 +770,20 @@ int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int la
 #undef EBM_TRY
     cleanup();
     return EBM_OK;
+}
+
+int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int lastonly,
+                  int winter_inx, int summer_inx, int nvars, const int *fields, double *raw,
+                  double *winter, double *summer, double *avg) {
+    return integrate_impl(h, nt, dur, f_steps, lastonly, winter_inx, summer_inx, nvars, fields, raw, winter, summer, avg,
+                          nullptr, nullptr, nullptr);
+}
+
+int ebm_integrate_hemispheric(ebm_handle_t h, int nt, int dur, const double *f_steps, int winter_inx, int summer_inx,
+                              int nvars, const int *fields, double *hm_winter, double *hm_summer, double *hm_avg) {
+    if (!hm_winter && !hm_summer && !hm_avg) return fail(EBM_ERR_ARG, "ebm_integrate_hemispheric: no output requested");
+    return integrate_impl(h, nt, dur, f_steps, 1, winter_inx, summer_inx, nvars, fields, nullptr, nullptr, nullptr, nullptr,
+                          hm_winter, hm_summer, hm_avg);
 }
 
 int ebm_sync(ebm_handle_t h) {

@@ -194,6 +194,20 @@ class Engine:
                                      dptr(summer), dptr(avg)), "ebm_integrate")
         return dict(raw=raw, winter=winter, summer=summer, avg=avg)
 
+    def integrate_hemispheric(self, nt, dur, f_steps, winter_inx, summer_inx, names):
+        """ebm_integrate_hemispheric: per variable, year and column the hemispheric mean (reference
+        src/utilities.jl:397-403) of the winter snapshot, the summer snapshot and the annual mean, reduced
+        on the device — dict(winter, summer, avg), each [nvars, dur, ncol].  The data of the reference's
+        hysteresis plot (src/plot.jl:173-225) for every column, without the fields crossing the bus."""
+        nv = len(names)
+        fields = (C.c_int * nv)(*[FIELD[n] for n in names])
+        f = None if f_steps is None else as_f64(f_steps, (nt * dur,))
+        out = {k: np.full((nv, dur, self.ncol), np.nan) for k in ("winter", "summer", "avg")}
+        check(self.lib.ebm_integrate_hemispheric(self._h, nt, dur, dptr(f), int(winter_inx), int(summer_inx), nv, fields,
+                                                 dptr(out["winter"]), dptr(out["summer"]), dptr(out["avg"])),
+              "ebm_integrate_hemispheric")
+        return out
+
     def sync(self):
         check(self.lib.ebm_sync(self._h), "ebm_sync")
 

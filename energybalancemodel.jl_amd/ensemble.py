@@ -73,6 +73,24 @@ class EnsembleRun:
         self.engine.run(self.step_index, nsteps, f, diag_last, steps_per_launch)
         self.step_index += nsteps
 
+    def seasonal_means(self, years, names=("T", "phi"), forcing=None):
+        """Integrate ``years`` whole years from the current state and return, per column, the
+        hemispheric means (reference src/utilities.jl:397-403) of the winter snapshot, the summer
+        snapshot and the annual mean of every variable in ``names`` for every year — reduced on the
+        device (ebm_integrate_hemispheric): dict(winter, summer, avg), each [len(names), years, ncol].
+        This is the data behind the reference's hysteresis plot (src/plot.jl:173-225: hemispheric_mean
+        of seasonal.avg.T[year] against 2*pi*hemispheric_mean of seasonal.{avg,winter,summer}.phi[year])
+        for every member, at O(members x years) bytes of I/O.  Model time (and with it the per-column
+        Forcing schedules) starts at 0 at the call, as in the reference's ``integrate``."""
+        st = self.st
+        f = None
+        if forcing is not None:
+            T = (np.arange(st.nt * years) + 0.5) * st.dt
+            f = np.array([forcing(float(t)) for t in T])
+        out = self.engine.integrate_hemispheric(st.nt, years, f, st.winter.inx, st.summer.inx, tuple(names))
+        self.step_index += st.nt * years
+        return out
+
     def state(self, names=None):
         return self.engine.get_state(names)
 

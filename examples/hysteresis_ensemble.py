@@ -47,17 +47,22 @@ def main():
                           device=int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0)
     if rank == 0:
         print(f"{args.members} members x {args.nlat} latitudes, {years} years of {args.nt} steps on {world} GPU(s)")
-    for year in range(years):
-        # forcing comes from the device schedules; nobody looks at the state inside a year: 64 steps per launch
-        run.run(args.nt, diag_last=True, steps_per_launch=64)
-        # per-member means reduced on the device, gathered to rank 0 as device tensors (RCCL), one host copy there
-        T = pkg.gather_columns(run.hemispheric_mean_tensor("T")[:, None], args.members, dist)
-        phi = pkg.gather_columns(run.hemispheric_mean_tensor("phi")[:, None], args.members, dist)
-        if rank == 0:
-            f_now = [f(year + 1.0 - 0.5 / args.nt) for f in forcings[:4]]
+    # One call for the whole experiment: savesol! runs inside the step kernel (annual-mean sums of T and phi,
+    # winter / summer snapshots), and only the per-member hemispheric means of those seasonal outputs — the
+    # numbers the reference's plot_seasonal draws (src/plot.jl:173-225) — leave the device.
+    hm = run.seasonal_means(years, ("T", "phi"))
+    # [variable, year, member] -> members first, gathered to rank 0 (device tensors over RCCL when sharded)
+    cols = {k: np.ascontiguousarray(np.moveaxis(v, 2, 0)) for k, v in hm.items()}
+    full = {k: pkg.gather_columns(v, args.members, dist) for k, v in cols.items()}
+    if rank == 0:
+        print("annual-mean hemispheric temperature and ice-covered area 2*pi*<phi> (annual mean / winter / summer), first 4 members")
+        for year in range(years):
+            f_now = [f(year + 0.5) for f in forcings[:4]]
+            Tm = full["avg"][:4, 0, year]
+            area = [2.0 * np.pi * full[k][:4, 1, year] for k in ("avg", "winter", "summer")]
             print(f"year {year + 1:3d}  f = " + " ".join(f"{v:5.2f}" for v in f_now) +
-                  "   <T> = " + " ".join(f"{v:6.2f}" for v in T[:4, 0]) +
-                  "   <phi> = " + " ".join(f"{v:5.3f}" for v in phi[:4, 0]))
+                  "   <T> = " + " ".join(f"{v:6.2f}" for v in Tm) +
+                  "   A_i = " + " ".join(f"{a:5.2f}/{w:5.2f}/{s_:5.2f}" for a, w, s_ in zip(*area)))
     run.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -169,6 +169,17 @@ int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int la
                   int winter_inx, int summer_inx, int nvars, const int *fields, double *raw,
                   double *winter, double *summer, double *avg);
 
+/* The same integration when only the HEMISPHERIC MEANS of the seasonal outputs are wanted — the numbers
+ * behind the reference's hysteresis plot (plot_seasonal, src/plot.jl:173-225: hemispheric_mean of
+ * seasonal.avg.T[year] and of seasonal.{avg,winter,summer}.phi[year]): per saved variable, year and column,
+ * hemispheric_mean (src/utilities.jl:397-403, the reference's summation order) of the winter snapshot, the
+ * summer snapshot and the annual mean, reduced on the device.  Outputs are [nvars][dur][ncol] host arrays
+ * (any may be NULL): O(columns x years) bytes cross the bus instead of O(state x years) — ensembles.
+ * Bit-identical to applying hemispheric_mean to ebm_integrate's winter / summer / avg outputs. */
+int ebm_integrate_hemispheric(ebm_handle_t h, int nt, int dur, const double *f_steps, int winter_inx,
+                              int summer_inx, int nvars, const int *fields, double *hm_winter,
+                              double *hm_summer, double *hm_avg);
+
 int ebm_sync(ebm_handle_t h);
 
 /* ---- measurement / diagnostics ------------------------------------------------------- */

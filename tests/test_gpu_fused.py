@@ -317,3 +317,46 @@ def test_diffusion_operator_is_bit_exact(pkg, oracle, kind, nlat):
     with make_engine(pkg, "Classic", st2, pkg.default_parameters("Classic"), 1) as eng:
         with pytest.raises(pkg.EBMError, match="MIZ handle"):
             eng.diffusion(np.zeros((1, nlat)))
+
+
+# ---- hemispheric means of the seasonal outputs, reduced on the device -----------
+@pytest.mark.parametrize("model,kind,nlat,ncol,nt,dur", [
+    ("MIZ", "sin", 180, 5, 2000, 2),              # the reference test's grid and time step
+    ("MIZ", "identity", 127, 2, 2000, 2),         # ragged
+    ("Classic", "identity", 180, 3, 400, 2),
+])
+def test_integrate_hemispheric_equals_host_means_of_the_fields(pkg, model, kind, nlat, ncol, nt, dur):
+    """ebm_integrate_hemispheric returns, per variable, year and column, hemispheric_mean
+    (src/utilities.jl:397-403) of the winter snapshot, the summer snapshot and the annual mean — what
+    the reference's plot_seasonal consumes (src/plot.jl:173-225) — reduced on the device.  It must equal,
+    bit for bit, the reference's sequential loop applied on the host to ebm_integrate's full fields,
+    NaN sentinels included, and leave the same final state."""
+    st = pkg.SpaceTime(kind, nlat, nt, dur)
+    par = pkg.default_parameters(model)
+    names = ("T", "phi", "E", "Ti") if model == "MIZ" else ("T", "E", "h")
+    f_steps = 0.8 * np.sin(np.arange(nt * dur) / 53.0)
+    fcol = np.linspace(-1.5, 1.5, ncol)
+    res = {}
+    for mode in ("fields", "means"):
+        with make_engine(pkg, model, st, par, ncol) as eng:
+            if model == "Classic":
+                eng.set_state(classic_init(pkg, st, par, ncol))
+            eng.set_column_forcing(fcol)
+            eng.set_time_table(st.t)
+            if mode == "fields":
+                out = eng.integrate(nt, dur, f_steps, True, st.winter.inx, st.summer.inx, names, want_raw=False)
+            else:
+                out = eng.integrate_hemispheric(nt, dur, f_steps, st.winter.inx, st.summer.inx, names)
+            res[mode] = (out, eng.get_state(names))
+    for k in ("winter", "summer", "avg"):
+        fields, means = res["fields"][0][k], res["means"][0][k]
+        assert means.shape == (len(names), dur, ncol)
+        with np.errstate(invalid="ignore"):
+            ref = pkg.hemispheric_mean(fields, st.x)             # [nvars, dur, ncol], sequential left-to-right sum
+        assert np.array_equal(means, ref, equal_nan=True), k
+    for v in names:
+        assert np.array_equal(res["fields"][1][v], res["means"][1][v], equal_nan=True), v
+    if model == "MIZ":
+        assert np.isnan(res["means"][0]["avg"][names.index("Ti")]).any()      # sentinels reach the means
+        phi_w = res["means"][0]["winter"][names.index("phi")]
+        assert np.isfinite(phi_w).all() and len(np.unique(phi_w[0])) == ncol     # a stable run; members differ
