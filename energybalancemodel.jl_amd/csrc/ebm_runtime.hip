@@ -421,8 +421,11 @@ int ebm_get_field(ebm_handle_t h, int field, double *host) {
     if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_get_field: field not part of this model");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy2D(host, sizeof(double) * h->nlat, h->field[field], sizeof(double) * h->pitch,
-                       sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToHost));
+    if (h->pitch == h->nlat)       // no padding: one contiguous copy
+        HIPCHK(hipMemcpy(host, h->field[field], sizeof(double) * (size_t)h->nlat * h->ncol, hipMemcpyDeviceToHost));
+    else
+        HIPCHK(hipMemcpy2D(host, sizeof(double) * h->nlat, h->field[field], sizeof(double) * h->pitch,
+                           sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToHost));
     return EBM_OK;
 }
 
