@@ -67,9 +67,10 @@ class COracle:
         self.lib.ebmo_thomas(C.c_int(len(b)), _ptr(a), _ptr(b), _ptr(c), _ptr(d), _ptr(xs))
         return xs
 
-    def miz_run(self, kind, x, par, dt, ct, ft, fcol, state, nthreads=1):
+    def miz_run(self, kind, x, par, dt, ct, ft, fcol, state, nthreads=1, imex=False):
         """state: dict of [ncol, nx] C-contiguous float64 arrays Ei,Ew,h,D,phi,T0 (updated in
-        place).  Returns dict of diagnostics Tw,Ti,n,E,T and counters (solves, failures)."""
+        place).  Returns dict of diagnostics Tw,Ti,n,E,T and counters (solves, failures).
+        imex=True: the implicit-diffusion extension (NOT the reference's scheme, see ebm_oracle.py)."""
         nx = len(x)
         ncol = state["Ei"].shape[0]
         for k in ("Ei", "Ew", "h", "D", "phi", "T0"):
@@ -86,7 +87,7 @@ class COracle:
             C.c_int(len(ct)), _ptr(ct), _ptr(ft), _ptr(fc),
             *[_ptr(state[k]) for k in ("Ei", "Ew", "h", "D", "phi", "T0")],
             *[_ptr(diag[k]) for k in ("Tw", "Ti", "n", "E", "T")],
-            counters, C.c_int(nthreads))
+            counters, C.c_int(nthreads), C.c_int(1 if imex else 0))
         return diag, (int(counters[0]), int(counters[1]))
 
     def T0eq(self, kind, x, par, ct, f, h, Ew, phi, T0):

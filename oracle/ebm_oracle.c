@@ -178,7 +178,7 @@ static inline real insolation(const real *p, real x, real ct) {
 static int miz_step_col(const Geom *g, const real *p, int nx, const real *x, real dt,
                         real ct, real f, real *Ei, real *Ew, real *h, real *D,
                         real *phi, real *T0, real *Tw_o, real *Ti_o, real *n_o,
-                        real *E_o, real *T_o, Work *w) {
+                        real *E_o, real *T_o, Work *w, int imex) {
     const real Tm = p[P_Tm], cw = p[P_cw], A = p[P_A], B = p[P_B], ai = p[P_ai];
     const real Lf = p[P_Lf], alpha = p[P_alpha], hmin = p[P_hmin], Dmin = p[P_Dmin];
     const real Dmax = p[P_Dmax], Fb = p[P_Fb];
@@ -230,6 +230,29 @@ static int miz_step_col(const Geom *g, const real *p, int nx, const real *x, rea
     const real c_weld = p[P_kappa] * alpha / 4.0;
     const real c_ht = -1.0 / Lf;
     const real two_rl = 2.0 * p[P_rl];
+    if (imex) {
+        /* EXTENSION, not in the reference: oracle/ebm_oracle.py:implicit_diffusion_correction (its
+         * definition).  dE = dt*(phi*Fvi + (1-phi)*Fvw), (I - (dt/cw)*Dif) dE_new = dE, and the diffusion
+         * term of both vertical fluxes below is corrected by (dE_new - dE)/dt.  Same expressions as the
+         * main loop. */
+        const real theta = dt / cw;
+        for (int k = 0; k < nx; ++k) {
+            const real xk = x[k], ph = phi[k];
+            real S = insolation(p, xk, ct);
+            real L = A + B * (w->tb[k] - Tm);
+            real sol_i = 0.0 + ai * S;
+            real sol_w = 0.0 + (p[P_a0] - p[P_a2] * (xk * xk)) * S;
+            real dif = diffusion_add(g, 0.0, w->tb, k);
+            real Fvi = sol_i - L + dif + Fb + f;
+            real Fvw = sol_w - L + dif + Fb + f;
+            w->d[k] = (ph * Fvi + (1.0 - ph) * Fvw) * dt;
+            w->a[k] = -(theta * g->lo[k]);
+            w->c[k] = -(theta * g->up[k]);
+            w->b[k] = 1.0 + theta * (g->lo[k] + g->up[k]);
+        }
+        thomas(nx, w->a, w->b, w->c, w->d, w->cp, w->dp, w->g);
+        for (int k = 0; k < nx; ++k) w->g[k] = (w->g[k] - w->d[k]) / dt;
+    }
     for (int k = 0; k < nx; ++k) {
         const real xk = x[k], ph = phi[k], hk = h[k], Dk = D[k], Tw = w->Tw[k], Ti = w->Ti[k];
         /* num :83-87 */
@@ -241,6 +264,7 @@ static int miz_step_col(const Geom *g, const real *p, int nx, const real *x, rea
         real sol_i = 0.0 + ai * S;
         real sol_w = 0.0 + (p[P_a0] - p[P_a2] * (xk * xk)) * S;
         real dif = diffusion_add(g, 0.0, w->tb, k);
+        if (imex) dif = dif + w->g[k];
         real Fvi = sol_i - L + dif + Fb + f;
         real Fvw = sol_w - L + dif + Fb + f;
         /* lat_flux :103-107, wlat :71 */
@@ -304,7 +328,7 @@ static int miz_run_impl(int kind, int nx, int ncol, const real *x, const real *p
                  int nsteps, const real *ct, const real *ft, const real *fcol,
                  real *Ei, real *Ew, real *h, real *D, real *phi, real *T0,
                  real *Tw, real *Ti, real *n, real *E, real *T, long long *counters,
-                 int nthreads) {
+                 int nthreads, int imex) {
     Geom g;
     geom_init(&g, kind, nx, x, par[P_D]);
     long long solves = 0, fails = 0;
@@ -323,7 +347,7 @@ static int miz_run_impl(int kind, int nx, int ncol, const real *x, const real *p
             for (int s = 0; s < nsteps; ++s) {
                 real f = fcol ? ft[s] + fcol[c] : ft[s];
                 int r = miz_step_col(&g, par, nx, x, dt, ct[s], f, Ei + o, Ew + o, h + o, D + o,
-                                     phi + o, T0 + o, Tw + o, Ti + o, n + o, E + o, T + o, &w);
+                                     phi + o, T0 + o, Tw + o, Ti + o, n + o, E + o, T + o, &w, imex);
                 solves += r < 0 ? -r : r;
                 fails += r < 0;
             }
@@ -479,11 +503,12 @@ void EBMO(thomas)(int n, const double *a, const double *b, const double *c, cons
     JUST_FREE(a); JUST_FREE(b); JUST_FREE(c); JUST_FREE(d); NARROW_FREE(xs, n);
 }
 
+/* imex != 0: the implicit-diffusion EXTENSION (see miz_step_col), not the reference's scheme */
 int EBMO(miz_run)(int kind, int nx, int ncol, const double *x, const double *par, double dt,
                   int nsteps, const double *ct, const double *ft, const double *fcol,
                   double *Ei, double *Ew, double *h, double *D, double *phi, double *T0,
                   double *Tw, double *Ti, double *n, double *E, double *T, long long *counters,
-                  int nthreads) {
+                  int nthreads, int imex) {
     const size_t N = (size_t)ncol * nx;
     (void)N;
     WIDEN(x, nx); WIDEN(par, P_COUNT); WIDEN(ct, nsteps); WIDEN(ft, nsteps); WIDEN(fcol, ncol);
@@ -491,7 +516,7 @@ int EBMO(miz_run)(int kind, int nx, int ncol, const double *x, const double *par
     WIDEN(Tw, N); WIDEN(Ti, N); WIDEN(n, N); WIDEN(E, N); WIDEN(T, N);
     int rc = miz_run_impl(kind, nx, ncol, RARG(x), RARG(par), dt, nsteps, RARG(ct), RARG(ft), RARG(fcol),
                           RARG(Ei), RARG(Ew), RARG(h), RARG(D), RARG(phi), RARG(T0), RARG(Tw), RARG(Ti),
-                          RARG(n), RARG(E), RARG(T), counters, nthreads);
+                          RARG(n), RARG(E), RARG(T), counters, nthreads, imex);
     JUST_FREE(x); JUST_FREE(par); JUST_FREE(ct); JUST_FREE(ft); JUST_FREE(fcol);
     NARROW_FREE(Ei, N); NARROW_FREE(Ew, N); NARROW_FREE(h, N); NARROW_FREE(D, N); NARROW_FREE(phi, N);
     NARROW_FREE(T0, N); NARROW_FREE(Tw, N); NARROW_FREE(Ti, N); NARROW_FREE(n, N); NARROW_FREE(E, N);

@@ -421,11 +421,37 @@ def D_t(h, D, Tw, phi, Ql, par):
     return lat_melt + lat_grow + weld
 
 
-def step_miz(ct, f, vars, T0_warm, x, dt, geom, par):
+def implicit_diffusion_correction(dE, dt, geom, par):
+    """EXTENSION, not in the reference — "parity unpinned" by construction; this
+    function IS its definition, the C oracle and the HIP kernel restate it.
+
+    The reference's step treats the meridional diffusion D d/dx[(1-x^2) dTbar/dx] inside the vertical
+    fluxes explicitly (src/miz.jl:96-101), which limits dt to cw*dx^2/(2D): more than 800,000 steps per
+    year at 4096 latitudes.  Linearly implicit correction: let dE = dt*(phi*Fvi + (1-phi)*Fvw) be the
+    explicit increment of a cell's TOTAL enthalpy (the lateral flux cancels in the sum) and assume the
+    surface temperature follows it with the water's heat capacity, u = dE_new/cw — an upper bound of the
+    true response (heat that melts or grows ice changes no temperature), which is what makes the scheme
+    stable.  Then dE_new = dE + dt*Dif(u), i.e.
+
+        (I - (dt/cw)*Dif) dE_new = dE          Dif = the operator's plain tridiagonal (lo, di, up)
+
+    one tridiagonal solve per meridian with a state-independent matrix, and the step continues with the
+    diffusion term of BOTH vertical fluxes corrected by (dE_new - dE)/dt.  Backward Euler on the diffusion
+    of the increment: no explicit limit from the grid spacing, first-order consistent with the reference's
+    step (the correction vanishes as dt -> 0)."""
+    theta = dt / par["cw"]
+    a = -(theta * geom.lo)
+    c = -(theta * geom.up)
+    b = 1.0 + theta * (geom.lo + geom.up)
+    return (thomas(a, b, c, dE) - dE) / dt
+
+
+def step_miz(ct, f, vars, T0_warm, x, dt, geom, par, imex=False):
     """One MIZ step, src/miz.jl:150-196.
 
     ``vars`` holds Ei, Ew, h, D, phi (1-D arrays).  Returns (new vars dict with all 10
-    variables, new warm start T0, n_solves, converged).  ``ct`` = cos(2.0*pi*t)."""
+    variables, new warm start T0, n_solves, converged).  ``ct`` = cos(2.0*pi*t).
+    ``imex=True``: the extension of implicit_diffusion_correction (NOT the reference's scheme)."""
     Ei, Ew, h, D, phi = (vars[k] for k in ("Ei", "Ew", "h", "D", "phi"))
     with np.errstate(all="ignore"):
         Tw = water_temp(Ew, phi, par)
@@ -434,6 +460,13 @@ def step_miz(ct, f, vars, T0_warm, x, dt, geom, par):
         n = num(D, phi, par)
         Fvi = vert_flux(x, ct, True, Ti, Tw, phi, f, geom, par)
         Fvw = vert_flux(x, ct, False, Ti, Tw, phi, f, geom, par)
+        if imex:
+            corr = implicit_diffusion_correction((phi * Fvi + (1.0 - phi) * Fvw) * dt, dt, geom, par)
+            tb = Tbar(Ti, Tw, phi)                               # vert_flux with dif + corr in place of dif
+            L = par["A"] + par["B"] * (tb - par["Tm"])
+            dif = geom.add(np.zeros_like(x), tb) + corr
+            Fvi = solar_add(np.zeros_like(x), x, ct, True, par) - L + dif + par["Fb"] + f
+            Fvw = solar_add(np.zeros_like(x), x, ct, False, par) - L + dif + par["Fb"] + f
         Flat = lat_flux(h, D, Tw, phi, par)
         rEi = Ei + (phi * Fvi + Flat) * dt
         rEw = Ew + ((1.0 - phi) * Fvw - Flat) * dt

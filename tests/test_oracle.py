@@ -276,7 +276,7 @@ def test_c_oracle_under_address_and_ub_sanitizers(tmp_path):
         #include <math.h>
         int ebmo_miz_run(int, int, int, const double *, const double *, double, int, const double *, const double *,
                          const double *, double *, double *, double *, double *, double *, double *, double *, double *,
-                         double *, double *, double *, long long *, int);
+                         double *, double *, double *, long long *, int, int);
         int ebmo_classic_run(int, int, const double *, const double *, double, int, const double *, const double *,
                              const double *, const double *, double *, double *, double *, double *, int);
         static const double par[25] = {0.6, 193.0, 2.1, 9.8, 420.0, 338.0, 240.0, 0.7, 0.1, 0.4, 4.0, 2.0, 9.5, 0.0, 0.098,
@@ -291,8 +291,9 @@ def test_c_oracle_under_address_and_ub_sanitizers(tmp_path):
                 double *f[11];
                 for (int i = 0; i < 11; ++i) f[i] = calloc((size_t)nx * ncol, sizeof(double));
                 long long cnt[2] = {0, 0};
-                ebmo_miz_run(kind, nx, ncol, x, par, 1.0 / 2000.0, nsteps, ct, ft, fcol, f[0], f[1], f[2], f[3], f[4], f[5],
-                             f[6], f[7], f[8], f[9], f[10], cnt, 1);
+                for (int imex = 0; imex < 2; ++imex)           /* the reference's scheme, then the implicit-diffusion extension */
+                    ebmo_miz_run(kind, nx, ncol, x, par, 1.0 / 2000.0, nsteps, ct, ft, fcol, f[0], f[1], f[2], f[3], f[4], f[5],
+                                 f[6], f[7], f[8], f[9], f[10], cnt, 1, imex);
                 printf("miz kind %d: solves %lld\\n", kind, cnt[0]);
                 for (int i = 0; i < 11; ++i) free(f[i]);
                 free(x); free(ct); free(ft);
