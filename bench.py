@@ -56,6 +56,9 @@ WORKLOADS = {
     "miz_1440x1": ("MIZ", "sin", 1440, 1, 131072),
     "miz_2048x4096": ("MIZ", "sin", 2048, 4096, 262144),     # same cells and bytes as the headline, half-length meridians
     "classic_1024x512": ("Classic", "identity", 1024, 512, 2000),
+    # the implicit-diffusion EXTENSION (not in the reference): the headline grid at the reference test's 2000
+    # steps per year, 520x beyond the explicit limit of the reference's own step
+    "miz_imex_4096x2048": ("MIZ_IMEX", "sin", 4096, 2048, 2000),
 }
 MIZ_VARS = ("E", "T", "h", "Ei", "Ew", "Ti", "Tw", "D", "phi", "n")
 
@@ -147,7 +150,7 @@ def main():
     integrate = args.workload.endswith("_integrate")
     K = max(1, args.steps_per_launch)
     st = pkg.SpaceTime(kind, nlat, nt, 1)
-    par = pkg.default_parameters(model)
+    par = pkg.default_parameters("MIZ" if model.startswith("MIZ") else model)
     lon = np.arange(ncol) + rank * ncol                      # this rank's block of columns
     if args.workload.startswith("miz_1024x512x32"):
         # BASELINE configs[4] / SURVEY 8(d) cfg5: 32 members of 512 meridians per GPU, member m of 256
@@ -240,7 +243,7 @@ def main():
     cpu = None
     ice_fraction = None
     host_transfer = None
-    if model == "MIZ":
+    if model.startswith("MIZ"):
         t0 = time.perf_counter()
         state = {k: eng.get_field(k) for k in ("Ei", "Ew", "h", "D", "phi", "T0")}
         dl = time.perf_counter() - t0
@@ -257,14 +260,14 @@ def main():
                                  "state_round_trip_ms / ms_per_step = steps a resident state must take per round trip "
                                  "for PCIe to cost as much as the stepping"}
         ice_fraction = float(np.mean(state["phi"] > 0))
-        if rank == 0 and world == 1 and args.cpu_budget > 0:
+        if rank == 0 and world == 1 and args.cpu_budget > 0 and model == "MIZ":
             cpu = cpu_baseline(pkg, wl, st, par, state, fcol, clock["step"], args.cpu_budget)
         del state
     eng.close()
 
     cells = nlat * ncol
     nsaved = len(MIZ_VARS) if integrate else 0
-    bpc = (BYTES_PER_CELL_STEP if model == "MIZ" else 32.0) + 16.0 * nsaved
+    bpc = (BYTES_PER_CELL_STEP if model.startswith("MIZ") else 32.0) + 16.0 * nsaved
     launches = cnt["launches"] / max(1, args.repeats)        # kernel launches per timed block
     ev_kernel_ms = max(ev_ms - (year_end_ms or 0.0), 1e-9)   # the step launches alone (integrate: without the year end)
     launch_s = ev_kernel_ms * 1e-3 / max(1.0, launches)
@@ -307,7 +310,7 @@ def main():
                            "means copied out at the end of every block" if integrate else ""),
             "steps_per_launch": (cnt["steps"] / cnt["launches"]) if cnt["launches"] else None,
             "ice_covered_fraction": ice_fraction,
-            "mean_tridiagonal_solves_per_column_step": (cnt["solves"] / (cnt["steps"] * ncol)) if model == "MIZ" and cnt["steps"] else 1.0,
+            "mean_tridiagonal_solves_per_column_step": (cnt["solves"] / (cnt["steps"] * ncol)) if model.startswith("MIZ") and cnt["steps"] else 1.0,
             "t0_cap_hits": cnt["cap_hits"],
             "threads_per_workgroup": info["threads"], "cells_per_thread": info["cells_per_thread"],
             "lds_bytes_per_workgroup": info["lds_bytes"],
@@ -316,7 +319,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": ("miz_fused_kernel" if K > 1 and info["threads"] <= 512 else "miz_step_kernel") if model == "MIZ" else "classic_step_kernel",
+            "kernel": ("miz_fused_kernel" if K > 1 and info["threads"] <= 512 else "miz_step_kernel") if model.startswith("MIZ") else "classic_step_kernel",
             "algorithmic_bytes_per_cell_step": bpc,
             "algorithmic_bytes_per_launch": bpc * cells * cnt["steps"] / max(1, cnt["launches"]),
             "avg_launch_ms": launch_s * 1e3,

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EBM_LIB") or os.path.join(_HERE, "libebm_hip.so")
 
 # enum ebm_model / ebm_grid / ebm_field / ebm_param (include/ebm_hip.h)
-MODEL = {"MIZ": 0, "Classic": 1}
+MODEL = {"MIZ": 0, "Classic": 1, "MIZ_IMEX": 2}     # MIZ_IMEX: extension, see include/ebm_hip.h
 GRID = {"identity": 0, "nonuniform": 1}
 FIELD = {"Ei": 0, "Ew": 1, "h": 2, "D": 3, "phi": 4, "T0": 5, "Tw": 6, "Ti": 7, "n": 8,
          "E": 9, "T": 10, "Tg": 11}

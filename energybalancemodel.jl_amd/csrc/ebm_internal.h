@@ -26,6 +26,7 @@ struct Params {
     // physics' IEEE division uses (derive_params_kernel), so that dividing through them gives the
     // bits an in-kernel division gives: 1/dt (src/miz.jl:173) and 1/c_dn (src/miz.jl:127).
     double rcp_dt, rcp_cdn;
+    double theta_imex;  // dt/cw: the implicit-diffusion extension's matrix is I - theta*Dif (EBM_MODEL_MIZ_IMEX)
 };
 
 // Device state: one slab, field slot s at state + s*fstride, each [ncol][pitch] with
@@ -109,7 +110,7 @@ constexpr int kFusedRegThreads = 512;   // up to here the fused-K kernel keeps t
 LaunchCfg choose_launch(int nlat, int ncol, int force_cells);
 hipError_t prepare_kernels(const LaunchCfg &cfg);   // raises the dynamic-LDS limit if needed
 // One workgroup per column.  mode: OutMode; OUT_LOOP runs a.nfused steps per launch.
-hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, hipStream_t s);
+hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, bool imex, hipStream_t s);
 hipError_t launch_classic_step(const StepArgs &a, int mode, const LaunchCfg &cfg, hipStream_t s);
 // rcp_dt / rcp_cdn of the device-resident parameter block (see Params)
 hipError_t launch_derive_params(Params *p_dev, hipStream_t s);

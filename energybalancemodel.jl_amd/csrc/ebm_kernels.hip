@@ -594,7 +594,14 @@ __device__ __forceinline__ void save_pair(const StepArgs &a, size_t col_off, uns
 //
 // OUT (OutMode): what is written besides the prognostics (OUT_STATE, OUT_DIAG, OUT_SAVE).
 // TT: workgroup size, a compile-time constant (LDS offsets become immediates).
-template <int C, int GRID, int OUT, int TT>
+//
+// IMEX: the implicit-diffusion EXTENSION (model EBM_MODEL_MIZ_IMEX; not in the reference — defined in
+// include/ebm_hip.h): before the cell updates the explicit increment of
+// every cell's total enthalpy, dE = dt*(phi*Fvi + (1-phi)*Fvw), goes through one more tridiagonal solve per
+// meridian, (I - (dt/cw)*Dif) dE_new = dE — the same partition + cyclic reduction as the T0 system — and the
+// diffusion term of both vertical fluxes is corrected by (dE_new - dE)/dt.  Lifts the explicit limit
+// dt <= cw*dx^2/(2D) of the reference's step.
+template <int C, int GRID, int OUT, int TT, bool IMEX>
 __global__ void __launch_bounds__(1024) miz_step_kernel(const StepArgs a) {
     static_assert(C == 2 || C == 4, "cells per thread");
     static_assert(OUT == OUT_STATE || OUT == OUT_DIAG || OUT == OUT_SAVE, "per-step kernel");
@@ -689,7 +696,7 @@ __global__ void __launch_bounds__(1024) miz_step_kernel(const StepArgs a) {
     load_chunk<C>(gX, k0, xk);
     const double xl = gX[k0 > 0 ? k0 - 1 : 0], xr = gX[k0 + C];     // zero-padded table; unused at the ends
     double g0[GRID == 0 ? C : 1], g1[GRID == 0 ? C : 1], g2[GRID == 0 ? C : 1];
-    if constexpr (GRID == 0) {
+    if constexpr (GRID == 0 && !IMEX) {
         // sub-, main and super-diagonal of par.D*get_diffop: on the identity grid the physics stencil
         // and the solver's plain coefficients are the same three tables (build_tables)
         load_chunk<C>(a.geom + G_LO * a.gstride, k0, g0);
@@ -719,6 +726,81 @@ __global__ void __launch_bounds__(1024) miz_step_kernel(const StepArgs a) {
     // out in two back-to-back 16-B stores once the second pair is done.
     double Fl = 0.0, xxl = 0.0;                           // flux / position of the interface left of the current cell
     if (GRID == 1) Fl = interface_flux((int)k0, nlat, xl, xk[0], tbl, tb[0], xxl);
+    double difx[IMEX ? C : 1];                            // IMEX: the corrected diffusion term of every cell
+    if constexpr (IMEX) {
+        // explicit D d/dx[(1-x^2) dTbar/dx] of every cell (the expressions of the loop below) and the explicit
+        // increment of its total enthalpy, dE = dt*(phi*Fvi + (1-phi)*Fvw)
+        auto increments = [&](double (&dif)[C], double (&dE)[C], const double hl, const double hr) {
+            double Fl_ = 0.0, xxl_ = 0.0;
+            if constexpr (GRID == 0) {                    // the three diagonals are fetched per use, not kept across the solve
+                unsigned kg = k0;
+                asm volatile("" : "+v"(kg));
+                load_chunk<C>(a.geom + G_LO * a.gstride, kg, g0);
+                load_chunk<C>(a.geom + G_DI * a.gstride, kg, g1);
+                load_chunk<C>(a.geom + G_UP * a.gstride, kg, g2);
+            }
+            if (GRID == 1) Fl_ = interface_flux((int)k0, nlat, xl, xk[0], hl, tb[0], xxl_);
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                const int k = (int)k0 + i;
+                const double tbm = i > 0 ? tb[i > 0 ? i - 1 : 0] : hl;
+                const double tbp = i < C - 1 ? tb[i < C - 1 ? i + 1 : i] : hr;
+                const double xp = i < C - 1 ? xk[i < C - 1 ? i + 1 : i] : xr;
+                if (GRID == 0) {
+                    dif[i] = diffusion_uniform(k, nlat, g0[GRID == 0 ? i : 0], g1[GRID == 0 ? i : 0],
+                                               g2[GRID == 0 ? i : 0], tbm, tb[i], tbp);
+                } else {
+                    double xxr;
+                    const double Fr = interface_flux(k + 1, nlat, xk[i], xp, tb[i], tbp, xxr);
+                    dif[i] = 0.0 + ieee_div(p.D * (Fr - Fl_), xxr - xxl_);               // :524
+                    Fl_ = Fr;
+                    xxl_ = xxr;
+                }
+                const double S = insolation(p, xk[i], ct);
+                const double L = p.A + p.B * (tb[i] - Tm);
+                const double sol_i = 0.0 + p.ai * S;
+                const double sol_w = 0.0 + (p.a0 - p.a2 * (xk[i] * xk[i])) * S;
+                const double Fvi = sol_i - L + dif[i] + p.Fb + f;
+                const double Fvw = sol_w - L + dif[i] + p.Fb + f;
+                // padding cells (k >= nlat; on a non-uniform grid their stencil is 0/0) must not reach the solve:
+                // their rows are decoupled but a NaN right-hand side would still spread through the elimination
+                dE[i] = k < nlat ? (ph[i] * Fvi + (1.0 - ph[i]) * Fvw) * p.dt : 0.0;
+            }
+        };
+        double sol[C];
+        {
+            // rows of I - (dt/cw)*Dif (padding rows: lo = up = 0, decoupled) and the right-hand side
+            double ra[C], rb[C], rc[C], dE[C], dif[C], tlo[C], tup[C];
+            load_chunk<C>(a.geom + G_LO * a.gstride, k0, tlo);
+            load_chunk<C>(a.geom + G_UP * a.gstride, k0, tup);
+            increments(dif, dE, tbl, tbr);
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                ra[i] = -(p.theta_imex * tlo[i]);
+                rc[i] = -(p.theta_imex * tup[i]);
+                rb[i] = 1.0 + p.theta_imex * (tlo[i] + tup[i]);
+            }
+            partition_solve<C>(ra, rb, rc, dE, sol, t, T, P0, P1);
+        }
+        __syncthreads();                                  // the solve's LDS reads are done before P0 is reused
+        {
+            // Only Ti (xs) and the solution crossed the solve in registers: phi, x and Tbar are fetched /
+            // formed again (the lane's cell index made opaque, so that the reloads are real), the Tbar halo
+            // is exchanged again, and the explicit terms are evaluated a second time — same operands, same
+            // operations, same bits — for the correction (dE_new - dE)/dt.
+            unsigned kl = k0;
+            asm volatile("" : "+v"(kl));
+            load_chunk<C>(st + S_phi * a.fstride, kl, ph);
+            load_chunk<C>(gX, kl, xk);
+#pragma unroll
+            for (int i = 0; i < C; ++i) tb[i] = xs[i] * ph[i] + (1.0 - ph[i]) * sTw[i * T];
+            double hl, hr, dE[C];
+            halo_exchange(P0, P0 + T, t, T, tb[0], tb[C - 1], hl, hr);
+            increments(difx, dE, hl, hr);
+#pragma unroll
+            for (int i = 0; i < C; ++i) difx[IMEX ? i : 0] = difx[IMEX ? i : 0] + div_with_rcp(sol[i] - dE[i], p.dt, p.rcp_dt);
+        }
+    }
     double *const park0 = P0 + 2 * T + t;                 // P0[2T..3T), P1[0..3T): clear of the halo words
 #pragma unroll
     for (int j = 0; j < C / 2; ++j) {
@@ -735,7 +817,9 @@ __global__ void __launch_bounds__(1024) miz_step_kernel(const StepArgs a) {
             const double xp = i < C - 1 ? xk[i < C - 1 ? i + 1 : i] : xr;
             const double S = insolation(p, xk[i], ct);
             double dif;
-            if (GRID == 0) {
+            if constexpr (IMEX) {
+                dif = difx[IMEX ? i : 0];
+            } else if (GRID == 0) {
                 dif = diffusion_uniform(k, nlat, g0[GRID == 0 ? i : 0], g1[GRID == 0 ? i : 0],
                                         g2[GRID == 0 ? i : 0], tbm, tb[i], tbp);
             } else {
@@ -1181,10 +1265,10 @@ using KernelFn = void (*)(const StepArgs);
 
 // Every workgroup size is compiled as a constant: T = 64 ... 1024 in steps of one wave (two cells per
 // thread: up to 512 threads).
-template <int C, int GRID, int OUT>
+template <int C, int GRID, int OUT, bool IMEX>
 KernelFn miz_kernel_for(int threads) {
     switch (threads) {
-#define EBM_CASE(TT) case TT: return miz_step_kernel<C, GRID, OUT, TT>;
+#define EBM_CASE(TT) case TT: return miz_step_kernel<C, GRID, OUT, TT, IMEX>;
 #ifdef EBM_QUICK   // development builds (tests/tools/resource_usage.py -DEBM_QUICK): three sizes only
         EBM_CASE(64) EBM_CASE(256) EBM_CASE(512)
 #else
@@ -1221,14 +1305,24 @@ KernelFn miz_fused_for(int threads) {
 template <int C, int GRID>
 KernelFn miz_kernel_cg(int mode, int threads) {
     switch (mode) {
-        case OUT_STATE: return miz_kernel_for<C, GRID, OUT_STATE>(threads);
-        case OUT_DIAG: return miz_kernel_for<C, GRID, OUT_DIAG>(threads);
-        case OUT_SAVE: return miz_kernel_for<C, GRID, OUT_SAVE>(threads);
+        case OUT_STATE: return miz_kernel_for<C, GRID, OUT_STATE, false>(threads);
+        case OUT_DIAG: return miz_kernel_for<C, GRID, OUT_DIAG, false>(threads);
+        case OUT_SAVE: return miz_kernel_for<C, GRID, OUT_SAVE, false>(threads);
         case OUT_LOOP: return miz_fused_for<C, GRID>(threads);   // more than kFusedRegThreads threads: no fused kernel (nullptr)
         default: return nullptr;
     }
 }
-KernelFn miz_kernel(int cells, int grid_kind, int mode, int threads) {
+template <int GRID>
+KernelFn miz_imex_kernel_g(int mode, int threads) {          // the extension: 4 cells per thread, one step per launch
+    switch (mode) {
+        case OUT_STATE: return miz_kernel_for<4, GRID, OUT_STATE, true>(threads);
+        case OUT_DIAG: return miz_kernel_for<4, GRID, OUT_DIAG, true>(threads);
+        case OUT_SAVE: return miz_kernel_for<4, GRID, OUT_SAVE, true>(threads);
+        default: return nullptr;
+    }
+}
+KernelFn miz_kernel(int cells, int grid_kind, int mode, int threads, bool imex) {
+    if (imex) return cells != 4 ? nullptr : (grid_kind == 0 ? miz_imex_kernel_g<0>(mode, threads) : miz_imex_kernel_g<1>(mode, threads));
     if (cells == 2) return grid_kind == 0 ? miz_kernel_cg<2, 0>(mode, threads) : miz_kernel_cg<2, 1>(mode, threads);
     return grid_kind == 0 ? miz_kernel_cg<4, 0>(mode, threads) : miz_kernel_cg<4, 1>(mode, threads);
 }
@@ -1256,17 +1350,19 @@ hipError_t prepare_kernels(const LaunchCfg &cfg) {
     if (cfg.lds_bytes <= 64 * 1024) return hipSuccess;
     for (int grid = 0; grid < 2; ++grid)
         for (int mode = OUT_STATE; mode <= OUT_SAVE; ++mode) {       // the fused kernel needs 6T doubles <= 24 KiB
-            KernelFn fn = miz_kernel(cfg.cells, grid, mode, cfg.threads);
-            if (!fn) return hipErrorInvalidValue;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
-            if (e != hipSuccess) return e;
+            for (int imex = 0; imex < (cfg.cells == 4 ? 2 : 1); ++imex) {
+                KernelFn fn = miz_kernel(cfg.cells, grid, mode, cfg.threads, imex != 0);
+                if (!fn) return hipErrorInvalidValue;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
+                if (e != hipSuccess) return e;
+            }
         }
     return hipSuccess;
 }
 
-hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, hipStream_t s) {
-    KernelFn fn = miz_kernel(cfg.cells, grid_kind, mode, cfg.threads);
+hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, bool imex, hipStream_t s) {
+    KernelFn fn = miz_kernel(cfg.cells, grid_kind, mode, cfg.threads, imex);
     if (!fn) return hipErrorInvalidValue;
     fn<<<dim3(a.ncol), dim3(cfg.threads), miz_lds_bytes(cfg, mode), s>>>(a);
     return hipGetLastError();

@@ -32,6 +32,7 @@ int fail(int code, const std::string &msg) {
 
 struct ebm_ctx {
     int model = 0, grid = 0, nlat = 0, ncol = 0, device = 0;
+    bool imex = false;                             // EBM_MODEL_MIZ_IMEX: model == EBM_MODEL_MIZ plus the implicit-diffusion extension
     long long pitch = 0;
     double dt = 0.0;
     ebm::Params p{};
@@ -175,6 +176,7 @@ void fill_params(ebm::Params &p, const double *v, double dt) {
     p.dc = p.dt_tau * p.cg_tau;
     p.M = p.B + p.cg_tau;
     p.kLf = p.k * p.Lf;
+    p.theta_imex = dt / p.cw;            // EBM_MODEL_MIZ_IMEX: the solve's matrix is I - theta*Dif
 }
 
 ebm::StepArgs base_args(const ebm_ctx *h) {
@@ -193,7 +195,7 @@ constexpr int kGraphSteps = 64;
 
 // mode: ebm::OutMode.  The classic kernel decides about T, h at run time (write_diag).
 hipError_t launch_step(ebm_ctx *h, const ebm::StepArgs &a, int mode) {
-    return (h->model == EBM_MODEL_MIZ) ? ebm::launch_miz_step(a, h->grid, mode, h->cfg, h->stream)
+    return (h->model == EBM_MODEL_MIZ) ? ebm::launch_miz_step(a, h->grid, mode, h->cfg, h->imex, h->stream)
                                        : ebm::launch_classic_step(a, mode, h->cfg, h->stream);
 }
 
@@ -304,7 +306,10 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
                const double *params, double dt, int device) {
     if (!out || !x || !params) return fail(EBM_ERR_ARG, "ebm_create: null argument");
     *out = nullptr;
-    if (model != EBM_MODEL_MIZ && model != EBM_MODEL_CLASSIC) return fail(EBM_ERR_ARG, "ebm_create: unknown model");
+    if (model != EBM_MODEL_MIZ && model != EBM_MODEL_CLASSIC && model != EBM_MODEL_MIZ_IMEX)
+        return fail(EBM_ERR_ARG, "ebm_create: unknown model");
+    const bool imex = model == EBM_MODEL_MIZ_IMEX;        // the extension is the MIZ model with one more solve per step
+    if (imex) model = EBM_MODEL_MIZ;
     if (grid != EBM_GRID_IDENTITY && grid != EBM_GRID_NONUNIFORM) return fail(EBM_ERR_ARG, "ebm_create: unknown grid kind");
     if (nlat < 2 || ncol < 1) return fail(EBM_ERR_ARG, "ebm_create: need nlat >= 2 and ncol >= 1");
     if (!(dt > 0.0)) return fail(EBM_ERR_ARG, "ebm_create: dt must be positive");
@@ -315,7 +320,7 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
         return fail(EBM_ERR_NO_DEVICE, "ebm_create: no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(EBM_ERR_ARG, "ebm_create: device index out of range");
     const char *cv = std::getenv("EBM_CELLS_PER_THREAD");    // testing knob: 2 or 4 cells per thread
-    ebm::LaunchCfg cfg = ebm::choose_launch(nlat, ncol, cv ? std::atoi(cv) : 0);
+    ebm::LaunchCfg cfg = ebm::choose_launch(nlat, ncol, imex ? 4 : (cv ? std::atoi(cv) : 0));   // the extension's kernels: 4 cells per thread
     if (cfg.threads == 0)
         return fail(EBM_ERR_UNSUPPORTED, "ebm_create: nlat > 4096 is not supported (one workgroup owns a whole meridian)");
     HIPCHK(hipSetDevice(device));
@@ -324,7 +329,7 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
     HIPCHK(hipGetDeviceProperties(&prop, device));
     ebm_ctx *h = new ebm_ctx();
     h->model = model; h->grid = grid; h->nlat = nlat; h->ncol = ncol; h->device = device;
-    h->dt = dt; h->cfg = cfg;
+    h->dt = dt; h->cfg = cfg; h->imex = imex;
     {
         h->num_cus = prop.multiProcessorCount;
         // a step of fewer than ~256K cells is launch-bound: replay graphs in ebm_run (EBM_GRAPH=0/1 overrides)
@@ -597,7 +602,7 @@ int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double
     if (h->ttab.empty()) return fail(EBM_ERR_ARG, "ebm_run_fused: call ebm_set_time_table first");
     // the fused MIZ kernel keeps the whole state in registers: up to kFusedRegThreads threads per
     // meridian (2048 cells at 4 per thread); longer meridians are stepped one launch per step
-    if (steps_per_launch == 1 || (h->model == EBM_MODEL_MIZ && h->cfg.threads > ebm::kFusedRegThreads))
+    if (steps_per_launch == 1 || h->imex || (h->model == EBM_MODEL_MIZ && h->cfg.threads > ebm::kFusedRegThreads))
         return ebm_run(h, first_step, nsteps, f_steps, diag_last);
     HIPCHK(hipSetDevice(h->device));
     if (!h->fused_sched) HIPCHK(hipMalloc(&h->fused_sched, sizeof(ebm::StepSched) * kFusedTable));

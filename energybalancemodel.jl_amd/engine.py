@@ -44,7 +44,7 @@ class Engine:
     def __init__(self, model: str, grid_kind: str, x, params25, dt: float, ncol: int = 1,
                  device: int = 0):
         if model not in MODEL:
-            raise ValueError(f"unknown model {model!r}: expected 'MIZ' or 'Classic'")
+            raise ValueError(f"unknown model {model!r}: expected 'MIZ', 'Classic' or the extension 'MIZ_IMEX'")
         self.lib = _lib.load()
         self.model, self.grid_kind = model, grid_kind
         self.x = as_f64(x)
@@ -79,11 +79,11 @@ class Engine:
     # -- state ------------------------------------------------------------------------
     @property
     def prognostic(self):
-        return MIZ_PROGNOSTIC if self.model == "MIZ" else CLASSIC_PROGNOSTIC
+        return MIZ_PROGNOSTIC if self.model.startswith("MIZ") else CLASSIC_PROGNOSTIC
 
     @property
     def diagnostic(self):
-        return MIZ_DIAGNOSTIC if self.model == "MIZ" else CLASSIC_DIAGNOSTIC
+        return MIZ_DIAGNOSTIC if self.model.startswith("MIZ") else CLASSIC_DIAGNOSTIC
 
     def set_field(self, name: str, values):
         a = as_f64(values).reshape(self.ncol, self.nlat)

@@ -186,11 +186,18 @@ class Solutions:
 
 MIZ_SOLVARS = ("E", "T", "h", "Ei", "Ew", "Ti", "Tw", "D", "phi", "n")
 CLASSIC_SOLVARS = ("E", "T", "h")
-_INIT_VARS = {"MIZ": ("Ei", "Ew", "h", "D", "phi"), "Classic": ("E", "Tg")}
+_INIT_VARS = {"MIZ": ("Ei", "Ew", "h", "D", "phi"), "Classic": ("E", "Tg"), "MIZ_IMEX": ("Ei", "Ew", "h", "D", "phi")}
+
+
+def _is_miz(model) -> bool:
+    """"MIZ" or "MIZ_IMEX" — the latter an EXTENSION with no counterpart in the reference: the MIZ model
+    with its meridional diffusion treated linearly implicitly (include/ebm_hip.h, EBM_MODEL_MIZ_IMEX), for
+    time steps beyond the explicit limit.  Pass ``default_parameters("MIZ")`` with it."""
+    return model in ("MIZ", "MIZ_IMEX")
 
 
 def _check_model(model):
-    if model not in ("MIZ", "Classic"):
+    if model not in ("MIZ", "Classic", "MIZ_IMEX"):
         # Julia: MethodError — no step!(::Val{model}, ...) method (src/infrastructure.jl:594)
         raise ValueError(f"no step! method for model {model!r}: expected 'MIZ' or 'Classic'")
 
@@ -243,16 +250,16 @@ def step_(model, t, f, vars, st, par, *, debug=None, verbose=False, device=0):
         eng = _step_engines[key] = _new_engine(model, st, par, 1, device)
     for k in _INIT_VARS[model]:
         eng.set_field(k, np.asarray(vars[k], dtype=np.float64).reshape(1, st.nx))
-    before = eng.counters()["cap_hits"] if (verbose and model == "MIZ") else 0
-    if model == "MIZ":
+    before = eng.counters()["cap_hits"] if (verbose and _is_miz(model)) else 0
+    if _is_miz(model):
         eng.step(cos2pit(t), 0.0, float(f), True)
     else:
         i = classic_time_index(t, st.dt, st.nt)                  # column of S, 1-based
         eng.step(cos2pit(float(st.t[i - 1])), cos2pit(float(st.t[i % st.nt])), float(f), True)
-    names = MIZ_SOLVARS if model == "MIZ" else ("E", "Tg", "T", "h")
+    names = MIZ_SOLVARS if _is_miz(model) else ("E", "Tg", "T", "h")
     for k in names:
         vars[k] = eng.get_field(k)[0]
-    if verbose and model == "MIZ" and eng.counters()["cap_hits"] > before:
+    if verbose and _is_miz(model) and eng.counters()["cap_hits"] > before:
         warnings.warn(f"Solving for T0 failed at t={t}.")        # src/miz.jl:61-63
     return vars
 
@@ -268,7 +275,7 @@ def integrate(model, st, forcing, par, init, *, lastonly=True, debug=None, verbo
     _check_model(model)
     if debug is not None:
         raise NotImplementedError("debug expressions cannot cross the C ABI (src/miz.jl:188-191)")
-    names = MIZ_SOLVARS if model == "MIZ" else CLASSIC_SOLVARS
+    names = MIZ_SOLVARS if _is_miz(model) else CLASSIC_SOLVARS
     sols = Solutions(st, forcing, par, init, names, lastonly, debug)
     f_steps = np.array([forcing(float(T)) for T in st.T], dtype=np.float64)
     with _new_engine(model, st, par, 1, device) as eng:

@@ -45,8 +45,21 @@ enum ebm_status {
     EBM_ERR_NO_DEVICE = -4 /* no usable GPU: the library never falls back to the CPU */
 };
 
-/* model tag == the Val{...} the reference dispatches step! on (src/infrastructure.jl:594) */
-enum ebm_model { EBM_MODEL_MIZ = 0, EBM_MODEL_CLASSIC = 1 };
+/* model tag == the Val{...} the reference dispatches step! on (src/infrastructure.jl:594).
+ *
+ * EBM_MODEL_MIZ_IMEX is an EXTENSION with no counterpart in the reference (and therefore no parity to
+ * claim): the MIZ model with its meridional diffusion treated linearly implicitly.  Each step the explicit
+ * increment of every cell's total enthalpy, dE = dt*(phi*Fvi + (1-phi)*Fvw), goes through one tridiagonal
+ * solve per meridian, (I - (dt/cw)*Dif) dE_new = dE, and the diffusion term of both vertical fluxes
+ * (src/miz.jl:96-101) is corrected by (dE_new - dE)/dt; everything else is the reference's step.  This lifts
+ * the explicit limit dt <= cw*dx^2/(2D) (more than 800,000 steps per year at 4096 latitudes) and converges
+ * to the reference's scheme as dt -> 0.  Dif is the operator D d/dx[(1-x^2) d/dx] as a plain tridiagonal
+ * matrix (zero-flux ends); assuming that the surface temperature follows the increment with the water's
+ * heat capacity cw is an upper bound of the true response (heat that melts or grows ice changes no
+ * temperature), which is what makes the scheme stable.  THIS TEXT IS THE DEFINITION.
+ * Same fields, parameters and entry points as EBM_MODEL_MIZ; one launch per step (ebm_run_fused does not
+ * fuse it). */
+enum ebm_model { EBM_MODEL_MIZ = 0, EBM_MODEL_CLASSIC = 1, EBM_MODEL_MIZ_IMEX = 2 };
 
 /* SpaceTime{identity} uses the sparse uniform-x operator (src/infrastructure.jl:495-497);
  * every other SpaceTime{F} (e.g. sin) the flux-form stencil (:505-526). */

@@ -422,8 +422,9 @@ def D_t(h, D, Tw, phi, Ql, par):
 
 
 def implicit_diffusion_correction(dE, dt, geom, par):
-    """EXTENSION, not in the reference — "parity unpinned" by construction; this
-    function IS its definition, the C oracle and the HIP kernel restate it.
+    """EXTENSION, not in the reference — "parity unpinned" by construction.  Defined in
+    include/ebm_hip.h (EBM_MODEL_MIZ_IMEX); this is the checker's restatement of that definition, the C
+    oracle restates it again, and the HIP kernel is compared with both.
 
     The reference's step treats the meridional diffusion D d/dx[(1-x^2) dTbar/dx] inside the vertical
     fluxes explicitly (src/miz.jl:96-101), which limits dt to cw*dx^2/(2D): more than 800,000 steps per
@@ -583,7 +584,7 @@ class Solutions:
         self.avg = {v: [None] * st.dur for v in varnames}
 
 
-def integrate(model, st, forcing, par, init, lastonly=True):
+def integrate(model, st, forcing, par, init, lastonly=True, imex=False):
     """integrate + savesol!, src/infrastructure.jl:549-591, 615-636.
 
     The classic branch drives step_classic directly (at the reference commit
@@ -605,7 +606,7 @@ def integrate(model, st, forcing, par, init, lastonly=True):
         ti = (tinx - 1) % nt + 1
         f = forcing(float(st.T[tinx - 1]))
         if model == "MIZ":
-            vars, T0, nit, ok = step_miz(ctab[ti - 1], f, vars, T0, x, dt, geom, par)
+            vars, T0, nit, ok = step_miz(ctab[ti - 1], f, vars, T0, x, dt, geom, par, imex=imex)
             stats["solves"] += nit
             stats["failures"] += 0 if ok else 1
         else:
