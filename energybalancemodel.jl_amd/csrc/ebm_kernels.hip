@@ -17,14 +17,15 @@
 //            floe size / thickness / concentration update, 16-byte stores
 //
 // Kernels in this file:
-//   miz_step_kernel<C, GRID, OUT, T>    one step per launch; OUT: state only / + diagnostics / savesol! from
-//                                       registers (annual-mean sums, raw snapshots)
+//   miz_step_kernel<C, GRID, OUT, T, IMEX>   one step per launch; OUT: state only / + diagnostics / savesol! from
+//                                       registers (annual-mean sums, raw snapshots); IMEX: the implicit-diffusion
+//                                       extension (one more tridiagonal solve per step, see include/ebm_hip.h)
 //   miz_fused_kernel<C, GRID, T>        K steps per launch, the whole state in registers (<= 512 threads)
 //   classic_step_kernel<C, MODE>        WE15 model: single step / savesol! / K steps per launch
 //   diffusion_kernel<GRID>              the diffusion operator on its own (ebm_diffusion)
 //   finish_mean, hemispheric_mean, mask_from_t0, derive_params, divide: small helpers
 // C = cells per thread (4; 2 for a few short meridians), GRID = 0 identity / 1 any other grid, T =
-// workgroup size as a compile-time constant.  Every instantiation uses 0 bytes of scratch
+// workgroup size as a compile-time constant.  Every one of the 285 instantiations uses 0 bytes of scratch
 // (tests/tools/resource_usage.py).
 //
 // Arithmetic policy.  Everything outside the tridiagonal solves is a bit-exact restatement of
