@@ -37,7 +37,11 @@ const PARAM_ORDER = (:D, :A, :B, :cw, :S0, :S1, :S2, :a0, :a2, :ai, :Fb, :k, :Lf
                      :Tm, :m1, :m2, :alpha, :rl, :Dmin, :Dmax, :hmin, :kappa)
 const FIELD = Dict(:Ei => 0, :Ew => 1, :h => 2, :D => 3, :phi => 4, :T0 => 5, :Tw => 6, :Ti => 7,
                    :n => 8, :E => 9, :T => 10, :Tg => 11)
-const MODEL = Dict(:MIZ => 0, :Classic => 1)
+const MODEL = Dict(:MIZ => 0, :Classic => 1, :MIZ_IMEX => 2)
+# :MIZ_IMEX is NOT a model of the reference: the MIZ model with its meridional diffusion treated implicitly
+# (EBM_MODEL_MIZ_IMEX in include/ebm_hip.h), for time steps beyond the explicit limit.  It exists only through
+# EBMHip.integrate / EBMHip.step!; pass default_parameters(:MIZ) with it.
+ismiz(model::Symbol) = model === :MIZ || model === :MIZ_IMEX
 
 struct EBMError <: Exception
     msg::String
@@ -90,8 +94,9 @@ cos2pit(t::Float64) = cos(2.0*pi * t)              # as written at src/miz.jl:11
 const _handles = Dict{UInt64,Handle}()
 handle_for(model, st, par) = get!(() -> Handle(model, st, par), _handles, hash((model, st.x, st.dt, parvec(par))))
 
-const INIT = Dict(:MIZ => (:Ei, :Ew, :h, :D, :phi), :Classic => (:E, :Tg))
-const OUT = Dict(:MIZ => (:Ei, :Ew, :h, :D, :phi, :Tw, :Ti, :n, :E, :T), :Classic => (:E, :Tg, :T, :h))
+const INIT = Dict(:MIZ => (:Ei, :Ew, :h, :D, :phi), :Classic => (:E, :Tg), :MIZ_IMEX => (:Ei, :Ew, :h, :D, :phi))
+const OUT = Dict(:MIZ => (:Ei, :Ew, :h, :D, :phi, :Tw, :Ti, :n, :E, :T), :Classic => (:E, :Tg, :T, :h),
+                 :MIZ_IMEX => (:Ei, :Ew, :h, :D, :phi, :Tw, :Ti, :n, :E, :T))
 
 """
     EBMHip.step!(Val(model), t, f, vars, st, par; debug=nothing, verbose=false) -> vars
@@ -107,12 +112,13 @@ function step!(::Val{M}, t::Float64, f::Float64, vars::Collection{Vec}, st::Spac
                debug::Union{Expr,Nothing}=nothing, verbose::Bool=false) where M
     model = M::Symbol
     if !isnothing(debug)      # the :Classic method has no `verbose` keyword at the reference commit (SURVEY F7)
+        model === :MIZ_IMEX && throw(ArgumentError("debug expressions need the reference's step!, which has no :MIZ_IMEX"))
         return model === :MIZ ? Infrastructure.step!(Val(model), t, f, vars, st, par; debug=debug, verbose=verbose) :
                                 Infrastructure.step!(Val(model), t, f, vars, st, par; debug=debug)
     end
     h = handle_for(model, st, par)
     foreach(k -> setfield_dev!(h, k, getproperty(vars, k)), INIT[model])
-    if model === :MIZ
+    if ismiz(model)
         ct, ctn = cos2pit(t), 0.0
     else
         i = round(Int, mod1((t + st.dt/2.0) * st.nt, st.nt))          # src/classic.jl:45
@@ -148,7 +154,7 @@ function integrate(model::Symbol, st::SpaceTime{F}, forcing::Forcing{C}, par::Co
                    device::Int=0)::Solutions{F,C} where {F, C}
     isnothing(debug) || return Infrastructure.integrate(model, st, forcing, par, init; lastonly=lastonly, debug=debug, verbose=verbose)
     solvars = Set{Symbol}((:E, :T, :h))                                     # src/infrastructure.jl:621-624
-    model === :MIZ && union!(solvars, Set{Symbol}((:Ei, :Ew, :Ti, :Tw, :D, :phi, :n)))
+    ismiz(model) && union!(solvars, Set{Symbol}((:Ei, :Ew, :Ti, :Tw, :D, :phi, :n)))
     sols = Solutions(st, forcing, par, init, solvars, lastonly)
     names = collect(solvars)
     h = Handle(model, st, par; device=device)          # owns the T0 warm start of this run (re-entrant, unlike src/miz.jl:47)

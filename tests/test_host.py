@@ -291,5 +291,5 @@ def test_julia_shim_enums_match_the_header():
               if f != "COUNT"]
     jl_fields = dict((k, int(v)) for k, v in re.findall(r":([A-Za-z0-9]+) => (\d+)", re.search(r"const FIELD = Dict\((.*?)\)\n", jl, flags=re.S).group(1)))
     assert jl_fields == {f: i for i, f in enumerate(fields)}
-    assert re.search(r"const MODEL = Dict\(:MIZ => 0, :Classic => 1\)", jl)
-    assert "EBM_MODEL_MIZ = 0, EBM_MODEL_CLASSIC = 1" in hdr
+    assert re.search(r"const MODEL = Dict\(:MIZ => 0, :Classic => 1, :MIZ_IMEX => 2\)", jl)
+    assert "EBM_MODEL_MIZ = 0, EBM_MODEL_CLASSIC = 1, EBM_MODEL_MIZ_IMEX = 2" in hdr
