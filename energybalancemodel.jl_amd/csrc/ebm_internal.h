@@ -101,7 +101,7 @@ struct LaunchCfg {
 
 constexpr int kCounterShards = 64;
 constexpr int kSchedWords = 9;     // base, peak, cool, rate up, rate down, domain[1..4]
-constexpr int kMaxNewton = 50;
+constexpr int kMaxNewton = 1000;   // the cap of the T0 iteration: NonlinearSolve's default maxiters (src/miz.jl:55-60 passes none)
 
 constexpr int kMaxLat = 4096;      // one workgroup of <= 1024 threads x 4 cells owns a whole meridian
 constexpr int kFusedRegThreads = 512;   // up to here the fused-K kernel keeps the whole state in registers

@@ -43,7 +43,7 @@ typedef double real;
 enum { P_D, P_A, P_B, P_cw, P_S0, P_S1, P_S2, P_a0, P_a2, P_ai, P_Fb, P_k, P_Lf, P_F, P_cg,
        P_tau, P_Tm, P_m1, P_m2, P_alpha, P_rl, P_Dmin, P_Dmax, P_hmin, P_kappa, P_COUNT };
 
-#define MAX_NEWTON 50
+#define MAX_NEWTON 1000   /* NonlinearSolve's default maxiters (src/miz.jl:55-60 passes none) */
 
 /* Julia min(::Float64, ::Float64): NaN-propagating, -0.0 < +0.0 */
 static inline real jl_min(real x, real y) {

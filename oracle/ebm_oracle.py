@@ -300,7 +300,7 @@ def thomas(a, b, c, d):
     return np.array(xs)
 
 
-MAX_NEWTON = 50
+MAX_NEWTON = 1000   # NonlinearSolve's default maxiters (src/miz.jl:55-60 passes none)
 
 
 def solve_T0(T0_warm, x, ct, hp, Tw, phi, f, geom, par):
