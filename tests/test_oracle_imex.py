@@ -101,3 +101,35 @@ def test_extension_lifts_the_grid_spacing_limit_on_dt(oracle, coracle):
     low, st_lo, _ = c_run(coracle, o, "sin", 180, 2000, 2000, False, 60.0, warm(180))
     assert all(np.isfinite(imex[k]).all() for k in PROG) and not (imex["phi"] > 0).any()
     assert abs(hm(imex, st_hi) - hm(low, st_lo)) < 0.3, (hm(imex, st_hi), hm(low, st_lo))
+
+
+def test_extension_reproduces_the_seasonal_climate_at_high_resolution(oracle, coracle):
+    """A realistic regime (warm start, default forcing: a seasonal ice cap): twelve years at 1024
+    latitudes with the extension and the reference test's 2000 steps per year (33x the explicit limit)
+    against the REFERENCE scheme at its own test resolution (180 latitudes, 2000 steps).  Quarterly
+    hemispheric means of T and of the ice concentration in year 12 agree to 0.15 K / 0.015; no T0
+    iteration reaches its cap."""
+    o = oracle
+    hm = lambda a, x: float(np.sum((np.nan_to_num(a[:-1]) + np.nan_to_num(a[1:])) * (x[1:] - x[:-1]) / 2.0))   # noqa: E731
+
+    def climate(nlat, imex):
+        st = o.SpaceTime("sin", nlat, 2000, 1)
+        par = o.default_parameters("MIZ")
+        s = {k: np.zeros((1, nlat)) for k in PROG + ("T0",)}
+        s["Ew"][0] = par["cw"] * np.maximum(30.0 - 45.0 * st.x ** 2, 0.0)
+        ct = np.array([o.cos2pit(float(t)) for t in st.t])
+        fails, quarters = 0, []
+        for year in range(12):
+            quarters = []
+            for q in range(4):
+                with np.errstate(all="ignore"):
+                    d, cnt = coracle.miz_run(1, st.x, dict(par), st.dt, ct[q * 500:(q + 1) * 500], np.zeros(500), None, s, imex=imex)
+                fails += cnt[1]
+                quarters.append((hm(d["T"][0], st.x), hm(s["phi"][0], st.x)))
+        assert all(np.isfinite(s[k]).all() for k in PROG) and fails == 0
+        return np.array(quarters)
+
+    ref, ext = climate(180, False), climate(1024, True)
+    assert np.max(np.abs(ext[:, 0] - ref[:, 0])) < 0.15, (ext[:, 0], ref[:, 0])
+    assert np.max(np.abs(ext[:, 1] - ref[:, 1])) < 0.015, (ext[:, 1], ref[:, 1])
+    assert ref[:, 1].max() > 0.1 and ref[:, 1].min() < 0.05          # a seasonal cycle of the ice cover is there
