@@ -53,6 +53,7 @@ WORKLOADS = {
     "miz_1024x512x32": ("MIZ", "sin", 1024, 512 * 32, 65536),
     "miz_1024x512x32_integrate": ("MIZ", "sin", 1024, 512 * 32, 65536),
     "miz_180x1": ("MIZ", "sin", 180, 1, 2000),               # the reference's own test / docstring shape
+    "miz_180x8192": ("MIZ", "sin", 180, 8192, 2000),         # an ensemble of it: 8192 members of the reference's resolution
     "miz_1440x1": ("MIZ", "sin", 1440, 1, 131072),
     "miz_2048x4096": ("MIZ", "sin", 2048, 4096, 262144),     # same cells and bytes as the headline, half-length meridians
     "classic_1024x512": ("Classic", "identity", 1024, 512, 2000),
