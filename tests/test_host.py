@@ -293,3 +293,47 @@ def test_julia_shim_enums_match_the_header():
     assert jl_fields == {f: i for i, f in enumerate(fields)}
     assert re.search(r"const MODEL = Dict\(:MIZ => 0, :Classic => 1, :MIZ_IMEX => 2\)", jl)
     assert "EBM_MODEL_MIZ = 0, EBM_MODEL_CLASSIC = 1, EBM_MODEL_MIZ_IMEX = 2" in hdr
+
+
+# ---- property tests of the host logic ------------------------------------------------------------------
+from hypothesis import given, settings, strategies as hst  # noqa: E402
+
+
+@settings(max_examples=200, deadline=None)
+@given(ncol=hst.integers(1, 5000), world=hst.integers(1, 64))
+def test_shard_columns_tiles_the_columns(pkg, ncol, world):
+    """Block partition: contiguous, disjoint, covering, sizes differing by at most one, the
+    larger blocks first."""
+    slices = [pkg.shard_columns(ncol, world, r) for r in range(world)]
+    assert slices[0].start == 0 and slices[-1].stop == ncol
+    assert all(a.stop == b.start for a, b in zip(slices, slices[1:]))
+    sizes = [s.stop - s.start for s in slices]
+    assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True) and sum(sizes) == ncol
+    with pytest.raises(ValueError):
+        pkg.shard_columns(ncol, world, world)
+
+
+@settings(max_examples=200, deadline=None)
+@given(base=hst.integers(-5, 5), up=hst.integers(1, 6), down=hst.integers(1, 6), hold0=hst.integers(0, 4),
+       hold1=hst.integers(0, 4), ru=hst.sampled_from([0.5, 1.0, 2.0]), rd=hst.sampled_from([0.5, 1.0, 2.0]),
+       T=hst.floats(0.0, 60.0))
+def test_forcing_is_the_references_piecewise_linear_schedule(pkg, oracle, base, up, down, hold0, hold1, ru, rd, T):
+    """Forcing(base, peak, cool, holdyrs, rates) (src/infrastructure.jl:208-241, :294-307): integer
+    breakpoints, hold / ramp up / hold / ramp down / hold, continuous, identical to the oracle's, and
+    the 9 schedule words the device evaluates reproduce it."""
+    peak, cool = base + up * ru, base + up * ru - down * rd
+    f = pkg.Forcing(float(base), peak, cool, (hold0, hold1), (ru, -rd))
+    g = oracle.Forcing(float(base), peak, cool, (hold0, hold1), (ru, -rd))
+    assert f.domain == g.domain == (0, hold0, hold0 + up, hold0 + up + hold1, hold0 + up + hold1 + down)
+    assert f(T) == g(T)
+    d = f.domain
+    for edge in d[1:]:                                           # continuity at the breakpoints
+        assert abs(f(edge) - f(np.nextafter(float(edge), -1.0))) < 1e-9 or edge == 0
+    assert f(0.0) == base and f(d[4] + 1.0) == cool and min(base, peak, cool) <= f(T) <= max(base, peak, cool)
+    from energybalancemodel_jl_amd.engine import schedule_words
+    w = schedule_words(f)
+    v = w[2] if T >= w[8] else (w[0] if T < w[5] else (w[0] + w[3] * (T - w[5]) if T < w[6] else
+                                                       (w[1] if T < w[7] else w[1] + w[4] * (T - w[7]))))
+    assert v == f(T)
+    with pytest.raises(ValueError):
+        pkg.Forcing(0.0, 1.0, 0.0, (1, 1), (0.3, -1.0))          # warming time 1/0.3 is not an integer
