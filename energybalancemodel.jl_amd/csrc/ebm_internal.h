@@ -110,6 +110,12 @@ constexpr int kFusedRegThreads = 512;   // up to here the fused-K kernel keeps t
 LaunchCfg choose_launch(int nlat, int ncol, int force_cells);
 hipError_t prepare_kernels(const LaunchCfg &cfg);   // raises the dynamic-LDS limit if needed
 // One workgroup per column.  mode: OutMode; OUT_LOOP runs a.nfused steps per launch.
+// The per-step MIZ kernels, one function per build part of ebm_kernels.hip (EBM_PART); nullptr = not compiled
+using KernelFn = void (*)(const StepArgs);
+KernelFn miz_step_kernels_identity(int cells, int mode, int threads);
+KernelFn miz_step_kernels_nonuniform(int cells, int mode, int threads);
+KernelFn miz_step_kernels_imex(int grid_kind, int mode, int threads);
+
 hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, bool imex, hipStream_t s);
 hipError_t launch_classic_step(const StepArgs &a, int mode, const LaunchCfg &cfg, hipStream_t s);
 // rcp_dt / rcp_cdn of the device-resident parameter block (see Params)

@@ -37,6 +37,23 @@
 // No MFMA: there is no dense contraction on this path; it is HBM-/fp64-VALU-bound.
 #include "ebm_internal.h"
 
+// EBM_PART: csrc/Makefile compiles this file once per part, in parallel, and links the objects — the MIZ
+// step kernel alone has 240 instantiations.  1 = its instantiations on the identity grid, 2 = on every other
+// grid, 3 = the implicit-diffusion extension, 0 = all other kernels and the launchers.  Undefined: one
+// translation unit with everything (tests/tools/resource_usage.py, A/B builds).
+#if !defined(EBM_PART) || EBM_PART == 0
+#define EBM_PART_MAIN 1
+#endif
+#if !defined(EBM_PART) || EBM_PART == 1
+#define EBM_PART_G0 1
+#endif
+#if !defined(EBM_PART) || EBM_PART == 2
+#define EBM_PART_G1 1
+#endif
+#if !defined(EBM_PART) || EBM_PART == 3
+#define EBM_PART_IMEX 1
+#endif
+
 namespace ebm {
 
 // Outputs are streamed: written once per step and not read again before the next launch.  With
@@ -1135,6 +1152,7 @@ __global__ void __launch_bounds__(1024) classic_step_kernel(const StepArgs a) {
     }
 }
 
+#ifdef EBM_PART_MAIN
 // Active set of a T0 field (after ebm_set_field(T0)): bit i of amask[col][t] <=> T0 < Tm in cell t*C+i.
 __global__ void mask_from_t0_kernel(const StepArgs a, int C) {
     const int T = blockDim.x, t = threadIdx.x, col = blockIdx.x;
@@ -1260,14 +1278,14 @@ LaunchCfg choose_launch(int nlat, int ncol, int force_cells) {
     return cfg;
 }
 
-namespace {
+#endif  // EBM_PART_MAIN
 
-using KernelFn = void (*)(const StepArgs);
+namespace {
 
 // Every workgroup size is compiled as a constant: T = 64 ... 1024 in steps of one wave (two cells per
 // thread: up to 512 threads).
 template <int C, int GRID, int OUT, bool IMEX>
-KernelFn miz_kernel_for(int threads) {
+[[maybe_unused]] KernelFn miz_kernel_for(int threads) {
     switch (threads) {
 #define EBM_CASE(TT) case TT: return miz_step_kernel<C, GRID, OUT, TT, IMEX>;
 #ifdef EBM_QUICK   // development builds (tests/tools/resource_usage.py -DEBM_QUICK): three sizes only
@@ -1290,6 +1308,38 @@ KernelFn miz_kernel_for(int threads) {
 #undef EBM_CASE
     return nullptr;
 }
+template <int C, int GRID, bool IMEX>
+[[maybe_unused]] KernelFn miz_step_by_mode(int mode, int threads) {
+    switch (mode) {
+        case OUT_STATE: return miz_kernel_for<C, GRID, OUT_STATE, IMEX>(threads);
+        case OUT_DIAG: return miz_kernel_for<C, GRID, OUT_DIAG, IMEX>(threads);
+        case OUT_SAVE: return miz_kernel_for<C, GRID, OUT_SAVE, IMEX>(threads);
+        default: return nullptr;
+    }
+}
+
+}  // namespace
+
+// The per-step MIZ kernels of one part (declared in ebm_internal.h, each defined in its own translation unit)
+#ifdef EBM_PART_G0
+KernelFn miz_step_kernels_identity(int cells, int mode, int threads) {
+    return cells == 2 ? miz_step_by_mode<2, 0, false>(mode, threads) : miz_step_by_mode<4, 0, false>(mode, threads);
+}
+#endif
+#ifdef EBM_PART_G1
+KernelFn miz_step_kernels_nonuniform(int cells, int mode, int threads) {
+    return cells == 2 ? miz_step_by_mode<2, 1, false>(mode, threads) : miz_step_by_mode<4, 1, false>(mode, threads);
+}
+#endif
+#ifdef EBM_PART_IMEX
+KernelFn miz_step_kernels_imex(int grid_kind, int mode, int threads) {        // the extension: 4 cells per thread
+    return grid_kind == 0 ? miz_step_by_mode<4, 0, true>(mode, threads) : miz_step_by_mode<4, 1, true>(mode, threads);
+}
+#endif
+
+#ifdef EBM_PART_MAIN
+namespace {
+
 template <int C, int GRID>
 KernelFn miz_fused_for(int threads) {
     switch (threads) {
@@ -1303,29 +1353,14 @@ KernelFn miz_fused_for(int threads) {
         default: return nullptr;
     }
 }
-template <int C, int GRID>
-KernelFn miz_kernel_cg(int mode, int threads) {
-    switch (mode) {
-        case OUT_STATE: return miz_kernel_for<C, GRID, OUT_STATE, false>(threads);
-        case OUT_DIAG: return miz_kernel_for<C, GRID, OUT_DIAG, false>(threads);
-        case OUT_SAVE: return miz_kernel_for<C, GRID, OUT_SAVE, false>(threads);
-        case OUT_LOOP: return miz_fused_for<C, GRID>(threads);   // more than kFusedRegThreads threads: no fused kernel (nullptr)
-        default: return nullptr;
-    }
-}
-template <int GRID>
-KernelFn miz_imex_kernel_g(int mode, int threads) {          // the extension: 4 cells per thread, one step per launch
-    switch (mode) {
-        case OUT_STATE: return miz_kernel_for<4, GRID, OUT_STATE, true>(threads);
-        case OUT_DIAG: return miz_kernel_for<4, GRID, OUT_DIAG, true>(threads);
-        case OUT_SAVE: return miz_kernel_for<4, GRID, OUT_SAVE, true>(threads);
-        default: return nullptr;
-    }
-}
 KernelFn miz_kernel(int cells, int grid_kind, int mode, int threads, bool imex) {
-    if (imex) return cells != 4 ? nullptr : (grid_kind == 0 ? miz_imex_kernel_g<0>(mode, threads) : miz_imex_kernel_g<1>(mode, threads));
-    if (cells == 2) return grid_kind == 0 ? miz_kernel_cg<2, 0>(mode, threads) : miz_kernel_cg<2, 1>(mode, threads);
-    return grid_kind == 0 ? miz_kernel_cg<4, 0>(mode, threads) : miz_kernel_cg<4, 1>(mode, threads);
+    if (mode == OUT_LOOP) {        // fused-K: not for the extension, not beyond kFusedRegThreads threads (nullptr)
+        if (imex) return nullptr;
+        if (cells == 2) return grid_kind == 0 ? miz_fused_for<2, 0>(threads) : miz_fused_for<2, 1>(threads);
+        return grid_kind == 0 ? miz_fused_for<4, 0>(threads) : miz_fused_for<4, 1>(threads);
+    }
+    if (imex) return cells != 4 ? nullptr : miz_step_kernels_imex(grid_kind, mode, threads);
+    return grid_kind == 0 ? miz_step_kernels_identity(cells, mode, threads) : miz_step_kernels_nonuniform(cells, mode, threads);
 }
 template <int C>
 KernelFn classic_kernel_c(int mode) {
@@ -1390,5 +1425,6 @@ hipError_t launch_finish_mean(double *dst, double *sum, double nt, int ncol, con
     finish_mean_kernel<<<ncol, cfg.threads, 0, s>>>(dst, sum, nt, cfg.threads, cfg.cells);
     return hipGetLastError();
 }
+#endif  // EBM_PART_MAIN
 
 }  // namespace ebm
