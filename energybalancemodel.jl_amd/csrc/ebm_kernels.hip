@@ -132,15 +132,25 @@ __device__ __forceinline__ double bool_mul(double x, bool b) {
 // v_div_fixup still produces the IEEE results for zero, infinite and NaN operands.
 // -DEBM_FULL_DIV selects the compiler's expansion instead.
 __device__ __forceinline__ double div_rcp(double b) {     // refined reciprocal of the sequence
+#if defined(EBM_TIMING_NO_TRANS)        // TIMING ONLY (results garbage): what the v_rcp_f64 themselves cost
+    const double r0 = __builtin_bit_cast(double, 0x7FDE6238502484BAll - __builtin_bit_cast(long long, b));   // +-12 %
+#else
     const double r0 = __builtin_amdgcn_rcp(b);
+#endif
+#if defined(EBM_TIMING_CHEAP_DIV)       // TIMING ONLY (results garbage): what all the refinement work costs
+    return r0;
+#else
     const double e0 = __builtin_fma(-b, r0, 1.0);
     const double r1 = __builtin_fma(r0, e0, r0);
     const double e1 = __builtin_fma(-b, r1, 1.0);
     return __builtin_fma(r1, e1, r1);
+#endif
 }
 __device__ __forceinline__ double div_with_rcp(double a, double b, double r2) {
-#ifdef EBM_FULL_DIV
+#if defined(EBM_FULL_DIV)
     return a / b;
+#elif defined(EBM_TIMING_CHEAP_DIV)
+    return a * r2;
 #else
     const double q0 = a * r2;
     const double rem = __builtin_fma(-b, q0, a);
