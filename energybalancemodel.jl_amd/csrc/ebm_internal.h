@@ -104,7 +104,9 @@ constexpr int kSchedWords = 9;     // base, peak, cool, rate up, rate down, doma
 constexpr int kMaxNewton = 1000;   // the cap of the T0 iteration: NonlinearSolve's default maxiters (src/miz.jl:55-60 passes none)
 
 constexpr int kMaxLat = 4096;      // one workgroup of <= 1024 threads x 4 cells owns a whole meridian
-constexpr int kFusedRegThreads = 512;   // up to here the fused-K kernel keeps the whole state in registers
+constexpr int kFusedRegThreads = 512;   // up to here the fused-K kernel keeps the whole state in registers (4 cells per thread)
+constexpr int kFusedRegThreads2 = 768;  // ... with 2 cells per thread (168 VGPRs: three waves per SIMD)
+constexpr int kMaxLat2 = 1536;          // longest meridian stepped with 2 cells per thread
 
 // force_cells: 0 = choose (4 cells per thread; 2 for a few short meridians), 2 / 4 = as told
 LaunchCfg choose_launch(int nlat, int ncol, int force_cells);

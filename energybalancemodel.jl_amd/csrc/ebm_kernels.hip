@@ -38,7 +38,7 @@
 #include "ebm_internal.h"
 
 // EBM_PART: csrc/Makefile compiles this file once per part, in parallel, and links the objects — the MIZ
-// step kernel alone has 240 instantiations.  1 = its instantiations on the identity grid, 2 = on every other
+// step kernel alone has 246 instantiations.  1 = its instantiations on the identity grid, 2 = on every other
 // grid, 3 = the implicit-diffusion extension, 0 = all other kernels and the launchers.  Undefined: one
 // translation unit with everything (tests/tools/resource_usage.py, A/B builds).
 #if !defined(EBM_PART) || EBM_PART == 0
@@ -1270,7 +1270,7 @@ __global__ void finish_mean_kernel(double *__restrict__ dst, double *__restrict_
 // ---- host-side launchers ----------------------------------------------------------------------
 // Cells per thread.  4 everywhere that throughput matters (32 contiguous bytes per lane and field).
 // A run of a few short meridians is latency-bound on a handful of waves: there 2 cells per thread put
-// twice as many SIMDs to work on every meridian (nlat <= 1024 so that the fused kernel still fits).
+// twice as many SIMDs to work on every meridian (nlat <= kMaxLat2 = 1536: the fused kernel then still fits three waves per SIMD).
 LaunchCfg choose_launch(int nlat, int ncol, int force_cells) {
     LaunchCfg cfg{};
     if (nlat > kMaxLat) {
@@ -1278,10 +1278,11 @@ LaunchCfg choose_launch(int nlat, int ncol, int force_cells) {
         return cfg;
     }
     int cells = 4;
-    if (nlat <= 1024 && (long long)ncol * ((nlat + 255) / 256) <= 128) cells = 2;
-    if ((force_cells == 2 && nlat <= 1024) || force_cells == 4) cells = force_cells;
+    if (nlat <= kMaxLat2 && (long long)ncol * ((nlat + 255) / 256) <= 128) cells = 2;
+    if ((force_cells == 2 && nlat <= kMaxLat2) || force_cells == 4) cells = force_cells;
     const int chunks = (nlat + cells - 1) / cells;
     cfg.threads = ((chunks + 63) / 64) * 64;
+    if (cells == 2 && cfg.threads > 512) cfg.threads = 768;     // the one size compiled beyond 512 (padding cells stay zero)
     cfg.cells = cells;
     // 2 x 3T cyclic reduction + the MIZ stash of Ew, h, Tw (3 C T)
     cfg.lds_bytes = sizeof(double) * (size_t)cfg.threads * (6 + 3 * (size_t)cells);
@@ -1293,7 +1294,7 @@ LaunchCfg choose_launch(int nlat, int ncol, int force_cells) {
 namespace {
 
 // Every workgroup size is compiled as a constant: T = 64 ... 1024 in steps of one wave (two cells per
-// thread: up to 512 threads).
+// thread: 64 ... 512, and 768 for every meridian of 1025 ... 1536 cells).
 template <int C, int GRID, int OUT, bool IMEX>
 [[maybe_unused]] KernelFn miz_kernel_for(int threads) {
     switch (threads) {
@@ -1304,6 +1305,9 @@ template <int C, int GRID, int OUT, bool IMEX>
         EBM_CASE(64) EBM_CASE(128) EBM_CASE(192) EBM_CASE(256) EBM_CASE(320) EBM_CASE(384) EBM_CASE(448) EBM_CASE(512)
 #endif
         default: break;
+    }
+    if constexpr (C == 2) {        // 1024 < nlat <= kMaxLat2: always 768 threads (choose_launch)
+        if (threads == 768) return miz_step_kernel<C, GRID, OUT, 768, IMEX>;
     }
     if constexpr (C == 4) {
         switch (threads) {
@@ -1359,9 +1363,13 @@ KernelFn miz_fused_for(int threads) {
 #else
         EBM_CASE(64) EBM_CASE(128) EBM_CASE(192) EBM_CASE(256) EBM_CASE(320) EBM_CASE(384) EBM_CASE(448) EBM_CASE(512)
 #endif
-#undef EBM_CASE
-        default: return nullptr;
+        default: break;
     }
+    if constexpr (C == 2) {        // 166 VGPRs: three waves per SIMD = kFusedRegThreads2 threads
+        if (threads == 768) return miz_fused_kernel<C, GRID, 768>;
+    }
+#undef EBM_CASE
+    return nullptr;
 }
 KernelFn miz_kernel(int cells, int grid_kind, int mode, int threads, bool imex) {
     if (mode == OUT_LOOP) {        // fused-K: not for the extension, not beyond kFusedRegThreads threads (nullptr)

@@ -602,7 +602,7 @@ int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double
     if (h->ttab.empty()) return fail(EBM_ERR_ARG, "ebm_run_fused: call ebm_set_time_table first");
     // the fused MIZ kernel keeps the whole state in registers: up to kFusedRegThreads threads per
     // meridian (2048 cells at 4 per thread); longer meridians are stepped one launch per step
-    if (steps_per_launch == 1 || h->imex || (h->model == EBM_MODEL_MIZ && h->cfg.threads > ebm::kFusedRegThreads))
+    if (steps_per_launch == 1 || h->imex || (h->model == EBM_MODEL_MIZ && h->cfg.threads > (h->cfg.cells == 2 ? ebm::kFusedRegThreads2 : ebm::kFusedRegThreads)))
         return ebm_run(h, first_step, nsteps, f_steps, diag_last);
     HIPCHK(hipSetDevice(h->device));
     if (!h->fused_sched) HIPCHK(hipMalloc(&h->fused_sched, sizeof(ebm::StepSched) * kFusedTable));

@@ -40,7 +40,9 @@ def classic_init(pkg, st, par, ncol):
     ("sin", 180, 3, 2000, 7),
     ("identity", 180, 2, 2000, 50),
     ("sin", 63, 2, 2000, 16),             # ragged single wave
-    ("sin", 1440, 1, 131072, 32),         # BASELINE configs[1]: six waves
+    ("sin", 1440, 1, 131072, 32),         # BASELINE configs[1]: six waves (twelve with two cells per thread)
+    ("identity", 1101, 2, 100000, 11),    # two cells per thread: 768 threads for 551 chunks
+    ("sin", 1536, 2, 150000, 6),          # the longest meridian with two cells per thread
     ("identity", 1000, 2, 60000, 5),
     ("sin", 2048, 3, 262144, 9),          # the largest meridian with a fused kernel (512 threads)
     ("sin", 2045, 2, 262144, 4),
@@ -50,8 +52,8 @@ def test_fused_run_equals_single_steps(pkg, kind, nlat, ncol, nt, K, cells):
     field — prognostics, the T0 of the last step, the diagnostics, NaN sentinels — is bitwise equal.
     Varying per-step forcing, per-column offsets, a run length that is not a multiple of K, a start
     late in the year (time index wraps), state handed over between two fused calls."""
-    if cells == 2 and nlat > 1024:
-        pytest.skip("two cells per thread exist up to 1024-cell meridians")
+    if cells == 2 and nlat > 1536:
+        pytest.skip("two cells per thread exist up to 1536-cell meridians")
     st = pkg.SpaceTime(kind, nlat, nt, 1)
     par = pkg.default_parameters("MIZ")
     nsteps = 3 * K + 5

@@ -269,6 +269,7 @@ def test_t0_solve_accuracy_extended_precision(pkg, oracle, coracle, kind, nlat, 
     ("identity", 257, 2, 8000, 10, 30, 5.7e-11),
     ("sin", 1000, 5, 60000, 20, 20, 6.7e-12),      # 256 threads, ragged
     ("sin", 1440, 2, 131072, 50, 20, 2.3e-12),     # BASELINE configs[1]: 1-D MIZ, 1440 bands
+    ("sin", 1101, 3, 100000, 30, 20, 1.6e-12),      # two cells per thread: 768 threads for 551 chunks (padding waves)
     ("identity", 1024, 8, 262144, 50, 20, 1.2e-13),  # nt: 2x the explicit stability limit cw dx^2/(2D)
     ("sin", 4096, 6, 1048576, 50, 10, 2.6e-13),    # BASELINE configs[3] meridian length, 1024 threads: the maximum
     ("sin", 4093, 2, 1048576, 20, 5, 1.1e-13),     # ragged at the maximum workgroup size
@@ -276,8 +277,8 @@ def test_t0_solve_accuracy_extended_precision(pkg, oracle, coracle, kind, nlat, 
 def test_miz_sizes_vs_oracle(pkg, coracle, kind, nlat, ncol, nt, spin, nsteps, measured, cells):
     """Spin up with the oracle (ice edge, open water and T0 solve all live), hand the state to
     the GPU, advance both, compare.  Per-column forcing differs per column."""
-    if cells == 2 and nlat > 1024:
-        pytest.skip("two cells per thread exist up to 1024-cell meridians")
+    if cells == 2 and nlat > 1536:
+        pytest.skip("two cells per thread exist up to 1536-cell meridians")
     st = pkg.SpaceTime(kind, nlat, nt, 1)
     par = pkg.default_parameters("MIZ")
     kid = 0 if kind == "identity" else 1
