@@ -1,0 +1,69 @@
+"""An anchor that does not pass through the oracle's author: an analytic solution of the model's own equations.
+
+Parity with the Julia package is unpinned in this pipeline (no Julia, golden file absent: DESIGN.md section 2), so
+the checker is a restatement by the same hand as the kernels.  This file holds the restatement — and, in
+tests/test_gpu_parity.py::test_explicit_step_reproduces_the_analytic_legendre_decay, the HIP path — to
+mathematics instead: on open water (phi = 0, Ew = cw*T > 0 so that no ice forms), without insolation
+(S0 = S1 = S2 = 0) and with A = Fb = f = 0, the MIZ model (src/miz.jl:96-101,137-138,166-167 with
+src/infrastructure.jl:495-526 for the diffusion) is
+
+    cw dT/dt = D d/dx[(1 - x^2) dT/dx] - B T        on x in [0, 1], symmetric at the equator,
+
+whose eigenfunctions are the even Legendre polynomials, d/dx[(1-x^2) P_n'] = -n(n+1) P_n.  One forward-Euler
+step of the reference multiplies the P_n component by exactly g_n = 1 - n(n+1)*lam - beta (lam = dt*D/cw,
+beta = dt*B/cw); what remains is the stencil's spatial error, second order on both grids.  This pins
+get_diffop / diffusion! (a7-a10), water_temp, Tbar, vert_flux and the forward-Euler update to the equations
+the reference discretises — not to its bits, which nothing here can."""
+import numpy as np
+import pytest
+
+PROG = ("Ei", "Ew", "h", "D", "phi")
+
+
+def legendre_setup(o, kind, nlat, nt, D=0.6, B=2.1):
+    st = o.SpaceTime(kind, nlat, nt, 1)
+    par = dict(o.default_parameters("MIZ"))
+    par.update(S0=0.0, S1=0.0, S2=0.0, A=0.0, B=B, Fb=0.0, D=D)
+    x = st.x
+    P2, P4 = (3 * x**2 - 1) / 2, (35 * x**4 - 30 * x**2 + 3) / 8
+    lam, beta = st.dt * D / par["cw"], st.dt * B / par["cw"]
+    g = [1 - m * lam - beta for m in (0, 6, 20)]                     # forward Euler, per step
+
+    def exact(n, amp=1.0):
+        return 10.0 * g[0]**n + np.multiply.outer(amp, P2 * g[1]**n + 0.5 * P4 * g[2]**n)
+    return st, par, exact
+
+
+def oracle_error(coracle, o, kind, nlat, nt, nsteps):
+    st, par, exact = legendre_setup(o, kind, nlat, nt)
+    s = {k: np.zeros((1, nlat)) for k in PROG + ("T0",)}
+    s["Ew"][0] = par["cw"] * exact(0)
+    with np.errstate(all="ignore"):
+        coracle.miz_run(0 if kind == "identity" else 1, st.x, par, st.dt, np.ones(nsteps), np.zeros(nsteps), None, s)
+    assert not s["Ei"].any() and not s["phi"].any()                  # stayed open water
+    return float(np.max(np.abs(s["Ew"][0] / par["cw"] - exact(nsteps))))
+
+
+@pytest.mark.parametrize("kind,limit", [("identity", 0.14), ("sin", 0.41)])
+def test_restated_explicit_step_has_the_analytic_decay_rates(oracle, coracle, kind, limit):
+    """A tenth of a year at a quarter of the explicit stability limit, 64 / 128 / 256 cells: P_2 has lost 5.7 %, P_4
+    13.4 %; distance to the analytic solution x nlat^2 is the same at every resolution (0.13 identity, 0.39 sin)."""
+    errs = [oracle_error(coracle, oracle, kind, n, nt, nt // 10) * n * n for n, nt in ((64, 2000), (128, 8000), (256, 32000))]
+    assert all(0.8 * limit < e < limit for e in errs), errs
+
+
+def test_numpy_restatement_agrees_on_the_manufactured_state(oracle, coracle):
+    """The NumPy restatement takes the same steps as the C one on this state (bit for bit, as on every other)."""
+    o = oracle
+    st, par, exact = legendre_setup(o, "sin", 96, 4000)
+    geom = o.DiffusionGeometry("sin", st.x, par["D"])
+    v, T0 = {k: np.zeros(96) for k in PROG}, np.zeros(96)
+    v["Ew"] = par["cw"] * exact(0)
+    s = {k: v[k][None].copy() for k in PROG}
+    s["T0"] = np.zeros((1, 96))
+    with np.errstate(all="ignore"):
+        for _ in range(50):
+            out, T0, _, _ = o.step_miz(1.0, 0.0, v, T0, st.x, st.dt, geom, par)
+            v = {k: out[k] for k in PROG}
+        coracle.miz_run(1, st.x, par, st.dt, np.ones(50), np.zeros(50), None, s)
+    assert np.array_equal(v["Ew"], s["Ew"][0])

@@ -823,3 +823,94 @@ def test_full_size_4096x2048_properties(pkg, coracle):
     ref = dict(state)
     ref.update(diag)
     check_all({k: got[k][sample] for k in ALL}, ref, 2e-11, what="4096x2048 sample")      # measured 2.0e-12
+
+
+# ---- an anchor outside the oracle: the analytic Legendre-mode decay (tests/test_analytic_solutions.py) ------------
+@pytest.mark.parametrize("kind,nlat,nt,nsteps,limit", [
+    ("identity", 256, 32000, 3200, 0.14),          # a tenth of a year at a quarter of the explicit limit: 0.132
+    ("sin", 256, 32000, 3200, 0.41),               # 0.395
+    ("sin", 1024, 512000, 12800, 0.12),            # a fortieth of a year, four waves per meridian: 0.108
+])
+def test_explicit_step_reproduces_the_analytic_legendre_decay(pkg, kind, nlat, nt, nsteps, limit, cells):
+    """Open water, no insolation, A = Fb = f = 0: cw dT/dt = D d/dx[(1-x^2) dT/dx] - B T.  One step of the reference's
+    scheme multiplies the P_n component of T by 1 - n(n+1) dt D/cw - dt B/cw exactly; the HIP path's distance to that
+    analytic solution is the second-order stencil's spatial error (x nlat^2: the measured constants above, the same
+    as the restatement's) — a check of a7-a10 and the open-water update that involves neither oracle nor author.
+    Columns carry different mode amplitudes (the problem is linear)."""
+    from test_analytic_solutions import legendre_setup
+    st, par, exact = legendre_setup(pkg, kind, nlat, nt)
+    amp = np.array([1.0, 0.25, 2.0])
+    state = {k: np.zeros((3, nlat)) for k in PROG + ("T0",)}
+    state["Ew"] = par["cw"] * exact(0, amp)
+    with make_engine(pkg, "MIZ", st, par, 3) as eng:
+        eng.set_state(state)
+        eng.set_time_table(st.t)
+        eng.run(0, nsteps)
+        got = eng.get_state(PROG)
+    assert not got["Ei"].any() and not got["phi"].any()              # stayed open water
+    err = float(np.max(np.abs(got["Ew"] / par["cw"] - exact(nsteps, amp)) / amp[:, None])) * nlat**2
+    record_error(f"analytic Legendre decay, {kind} {nlat}, {nsteps} steps: error x nlat^2", "Ew/cw", err, limit)
+    assert 0.5 * limit < err < limit, err
+
+
+def test_step1_closed_forms_on_the_gpu(pkg, cells):
+    """The closed forms of step 1 from the all-zero state (test/runtests.jl:24-31; derived from src/miz.jl:156-187 in
+    SURVEY 8c), checked on the HIP path directly — no oracle in between: Tw = Ti = n = Flat = 0,
+    Fvw = (a0 - a2 x^2) S - A + Fb; cells with rEw = dt Fvw < 0 freeze: Ei = rEw, Ew = 0, D = Dmin, h = hmin,
+    phi = min(1, -Ei/(Lf hmin)); the others keep Ew = rEw.  Sentinels of src/miz.jl:193-194."""
+    st = pkg.SpaceTime("sin", 180, 2000, 1)
+    par = pkg.default_parameters("MIZ")
+    with make_engine(pkg, "MIZ", st, par, 1) as eng:
+        eng.set_time_table(st.t)
+        eng.run(0, 1, None, True)
+        out = {k: v[0] for k, v in eng.get_state(ALL).items()}
+    x, ct = st.x, pkg.cos2pit(float(st.t[0]))
+    S = par["S0"] - par["S1"] * x * ct - par["S2"] * x * x
+    rEw = st.dt * ((par["a0"] - par["a2"] * x * x) * S - par["A"] + par["Fb"])
+    frz = rEw < 0
+    assert frz.any() and (~frz).any() and np.all(out["n"] == 0.0)
+    np.testing.assert_allclose(out["Ei"][frz], rEw[frz], rtol=1e-13)
+    np.testing.assert_allclose(out["Ew"][~frz], rEw[~frz], rtol=1e-13)
+    assert np.all(out["Ew"][frz] == 0.0) and np.all(out["Ei"][~frz] == 0.0)
+    assert np.all(out["D"][frz] == par["Dmin"]) and np.all(out["D"][~frz] == 0.0)
+    np.testing.assert_allclose(out["h"][frz], par["hmin"], rtol=1e-13)
+    np.testing.assert_allclose(out["phi"][frz], np.minimum(1.0, -rEw[frz] / (par["Lf"] * par["hmin"])), rtol=1e-12)
+    assert np.all(np.isnan(out["Ti"][~frz])) and not np.isnan(out["Ti"][frz]).any()
+    assert np.all(out["Tw"][out["phi"] <= 0.99] == 0.0)               # old Tw (zero state), not a sentinel there
+
+
+@pytest.mark.parametrize("kind,nlat", [("sin", 180), ("identity", 1000), ("sin", 4096)])
+def test_t0_without_diffusion_is_the_pointwise_closed_form(pkg, kind, nlat, cells):
+    """With D = 0 the ice-surface balance of src/miz.jl:33-43 decouples:
+    k (Tm - T0)/h' + ai S - A - B (T0 - Tm) + f = 0, h' = (h == 0 ? hmin : h)  =>  T0 - Tm = (ai S - A + f)/(k/h' + B),
+    whatever the active set.  The HIP path's T0 (partition + cyclic reduction on a diagonal system, through the
+    active-set iteration) against that closed form — no oracle involved."""
+    if cells == 2 and nlat > 1536:
+        pytest.skip("two cells per thread exist up to 1536-cell meridians")
+    st = pkg.SpaceTime(kind, nlat, 2000, 1)
+    par = dict(pkg.default_parameters("MIZ"))
+    par["D"] = 0.0
+    rng = np.random.default_rng(nlat)
+    ice = rng.random((2, nlat)) < 0.7
+    h = np.where(ice, rng.uniform(0.1, 4.0, (2, nlat)), 0.0)
+    phi = np.where(ice, rng.uniform(0.05, 1.0, (2, nlat)), 0.0)
+    state = {"h": h, "phi": phi, "Ei": -par["Lf"] * h * phi, "D": np.where(ice, 50.0, 0.0),
+             "Ew": np.where(phi < 1.0, rng.uniform(0.0, 5.0, (2, nlat)), 0.0), "T0": np.zeros((2, nlat))}
+    fcol = np.array([-3.0, 40.0])                                    # column 1: strong forcing, surface at the melting point in places
+    with make_engine(pkg, "MIZ", st, par, 2) as eng:
+        eng.set_state(state)
+        eng.set_column_forcing(fcol)
+        eng.set_time_table(st.t)
+        eng.run(700, 1, None, True)                                  # t = 0.35: sun up in the north
+        T0 = eng.get_field("T0")
+        Ti = eng.get_field("Ti")
+        cnt = eng.counters()
+    x, ct = st.x, pkg.cos2pit(float(st.t[700]))
+    S = par["S0"] - par["S1"] * x * ct - par["S2"] * x * x
+    hp = np.where(h == 0.0, par["hmin"], h)
+    want = par["Tm"] + (par["ai"] * S - par["A"] + fcol[:, None]) / (par["k"] / hp + par["B"])
+    err = float(np.max(np.abs(T0 - want) / np.maximum(1.0, np.abs(want))))
+    record_error(f"T0 closed form without diffusion, {kind} {nlat}", "T0", err, 1e-13)
+    assert err <= 1e-13, err
+    assert (want > par["Tm"]).any() and (want < par["Tm"]).any() and cnt["cap_hits"] == 0
+    np.testing.assert_array_equal(Ti[ice], np.minimum(T0, par["Tm"])[ice])    # ice_temp, zeroref!: src/miz.jl:31,65-66

@@ -133,3 +133,63 @@ def test_extension_reproduces_the_seasonal_climate_at_high_resolution(oracle, co
     assert np.max(np.abs(ext[:, 0] - ref[:, 0])) < 0.15, (ext[:, 0], ref[:, 0])
     assert np.max(np.abs(ext[:, 1] - ref[:, 1])) < 0.015, (ext[:, 1], ref[:, 1])
     assert ref[:, 1].max() > 0.1 and ref[:, 1].min() < 0.05          # a seasonal cycle of the ice cover is there
+
+
+# ---- manufactured solution (SURVEY 8(f) rank 4 asks for one) -----------------------------------
+# Open water everywhere (phi = 0, Ew = cw*T > 0: no ice forms), no insolation (S0 = S1 = S2 = 0), A = Fb = f = 0:
+# the model is cw dT/dt = D d/dx[(1-x^2) dT/dx] - B T on x in [0, 1], whose eigenfunctions are the even Legendre
+# polynomials, d/dx[(1-x^2) P_n'] = -n(n+1) P_n (symmetric at the equator, regular at the pole).  With
+# lam = dt*D/cw, beta = dt*B/cw the extension's step — explicit in everything, implicit in the meridional
+# diffusion of the increment — multiplies the P_n component by exactly
+#     g_n = 1 - (n(n+1)*lam + beta) / (1 + n(n+1)*lam)        (backward Euler in the diffusion for beta = 0)
+# whatever the size of lam; the explicit scheme of the reference needs lam <= dx^2/2.
+def legendre_case(o, kind, nlat, nt, D, B):
+    st = o.SpaceTime(kind, nlat, nt, 1)
+    par = dict(o.default_parameters("MIZ"))
+    par.update(S0=0.0, S1=0.0, S2=0.0, A=0.0, B=B, Fb=0.0, D=D)
+    x = st.x
+    P2, P4 = (3 * x**2 - 1) / 2, (35 * x**4 - 30 * x**2 + 3) / 8
+    lam, beta = st.dt * D / par["cw"], st.dt * B / par["cw"]
+
+    def exact(n):
+        g = [1 - (m * lam + beta) / (1 + m * lam) for m in (0, 6, 20)]
+        return 10.0 * g[0]**n + P2 * g[1]**n + 0.5 * P4 * g[2]**n
+    return st, par, exact, lam
+
+
+def legendre_run(coracle, o, kind, nlat, nt, D, B, nsteps):
+    st, par, exact, lam = legendre_case(o, kind, nlat, nt, D, B)
+    s = {k: np.zeros((1, nlat)) for k in PROG + ("T0",)}
+    s["Ew"][0] = par["cw"] * exact(0)
+    with np.errstate(all="ignore"):
+        coracle.miz_run(0 if kind == "identity" else 1, st.x, par, st.dt, np.ones(nsteps), np.zeros(nsteps), None, s, imex=True)
+    assert not s["Ei"].any() and not s["phi"].any()                  # stayed open water
+    return float(np.max(np.abs(s["Ew"][0] / par["cw"] - exact(nsteps)))), lam
+
+
+@pytest.mark.parametrize("kind", ["identity", "sin"])
+@pytest.mark.parametrize("B", [0.0, 2.1])
+def test_manufactured_legendre_modes_decay_at_the_analytic_rate(oracle, coracle, kind, B):
+    """Five steps at lam = 0.061 — 2 000 (64 cells) to 32 000 (256 cells) times the explicit limit dx^2/2: the
+    P_2 and P_4 components have decayed to 21 % and 4 % by the analytic factors; the error is the spatial
+    discretisation's and falls by 4 per doubling of the grid (second order) on both grids."""
+    errs = [legendre_run(coracle, oracle, kind, n, 100, 60.0, B, 5)[0] for n in (64, 128, 256)]
+    assert errs[0] < (2e-3 if kind == "sin" else 6e-4)
+    for coarse, fine in zip(errs, errs[1:]):
+        assert 3.7 < coarse / fine < 4.3, errs
+
+
+def test_manufactured_solution_is_first_order_in_time(oracle, coracle):
+    """Against the continuous-time solution exp(-n(n+1) D t / cw): to t = 0.05 yr in 5, 10, 20 steps the error halves
+    with the step (the spatial error at 512 cells is far below)."""
+    o, D, errs = oracle, 60.0, []
+    for nt, n in ((100, 5), (200, 10), (400, 20)):
+        st, par, _, _ = legendre_case(o, "identity", 512, nt, D, 0.0)
+        x, t = st.x, n * st.dt
+        cont = 10.0 + (3 * x**2 - 1) / 2 * np.exp(-6 * D * t / par["cw"]) + 0.5 * (35 * x**4 - 30 * x**2 + 3) / 8 * np.exp(-20 * D * t / par["cw"])
+        s = {k: np.zeros((1, 512)) for k in PROG + ("T0",)}
+        s["Ew"][0] = par["cw"] * (10.0 + (3 * x**2 - 1) / 2 + 0.5 * (35 * x**4 - 30 * x**2 + 3) / 8)
+        with np.errstate(all="ignore"):
+            coracle.miz_run(0, st.x, par, st.dt, np.ones(n), np.zeros(n), None, s, imex=True)
+        errs.append(float(np.max(np.abs(s["Ew"][0] / par["cw"] - cont))))
+    assert 1.7 < errs[0] / errs[1] < 2.3 and 1.7 < errs[1] / errs[2] < 2.3, errs
