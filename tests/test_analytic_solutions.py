@@ -67,3 +67,47 @@ def test_numpy_restatement_agrees_on_the_manufactured_state(oracle, coracle):
             v = {k: out[k] for k in PROG}
         coracle.miz_run(1, st.x, par, st.dt, np.ones(50), np.zeros(50), None, s)
     assert np.array_equal(v["Ew"], s["Ew"][0])
+
+
+# ---- classic (WE15) model, src/classic.jl:37-71: open water everywhere (E > 0), S = 0, A = Fb = f = 0 ----------------
+# alpha = aw, T = E/cw, C = (cg/tau) Tg, and with M = B + cg/tau the step is linear:
+#     E'  = E + dt ((cg/tau) Tg - M E/cw)                                   forward Euler, pointwise (:53)
+#     Tg' = kappa^-1 (Tg + (dt/tau) E'/cw),  kappa = (1 + dt/tau) I - dt D/cg get_diffop      implicit Euler (:55-63, :21)
+# so the P_n amplitudes (e of E/cw, g of Tg) follow the 2x2 recurrence
+#     e' = e + dt ((cg/tau) g - M e)/cw,      g' = (g + (dt/tau) e') / (1 + dt/tau + n(n+1) dt D/cg)
+# exactly; what is left is the spatial error of get_diffop in the implicit solve.
+def classic_setup(o, nlat, nt):
+    st = o.SpaceTime("identity", nlat, nt, 1)
+    par = dict(o.default_parameters("Classic"))
+    par.update(S0=0.0, S1=0.0, S2=0.0, A=0.0, Fb=0.0)
+    x = st.x
+    modes = [np.ones(nlat), (3 * x**2 - 1) / 2, (35 * x**4 - 30 * x**2 + 3) / 8]
+    e0, g0 = np.array([10.0, 1.0, 0.5]), np.array([8.0, -0.6, 0.8])
+
+    def exact(n, amp=1.0):
+        e, g = e0.copy(), g0.copy()
+        cgt, dtt = par["cg"] / par["tau"], st.dt / par["tau"]
+        M = par["B"] + cgt
+        mu = np.array([0.0, 6.0, 20.0])
+        for _ in range(n):
+            e = e + st.dt * (cgt * g - M * e) / par["cw"]
+            g = (g + dtt * e) / (1.0 + dtt + mu * st.dt * par["D"] / par["cg"])
+        field = lambda c: c[0] * modes[0] + np.multiply.outer(amp, c[1] * modes[1] + c[2] * modes[2])
+        return field(e), field(g)
+    return st, par, exact
+
+
+@pytest.mark.parametrize("nlat", [64, 256])
+def test_restated_classic_step_follows_the_analytic_mode_recurrence(oracle, coracle, nlat):
+    """200 steps of 1/2000 yr (the classic model's implicit ghost layer has no stability limit): E/cw and Tg against
+    the mode recurrence; the error is get_diffop's, second order: x nlat^2 it is the same on 64 and on 256 cells."""
+    st, par, exact = classic_setup(oracle, nlat, 2000)
+    n = 200
+    T, G = exact(0)
+    s = dict(E=(par["cw"] * T)[None].copy(), Tg=G[None].copy())
+    out = coracle.classic_run(st.x, par, st.dt, np.ones(n), np.ones(n), np.zeros(n), None, s)
+    s.update(out)
+    assert (s["E"] > 0).all() and not s["h"].any()
+    Tn, Gn = exact(n)
+    err = max(np.max(np.abs(s["E"][0] / par["cw"] - Tn)), np.max(np.abs(s["Tg"][0] - Gn))) * nlat**2
+    assert 0.15 < err < 0.18, err                                    # measured 0.164 (64), 0.167 (256)

@@ -914,3 +914,25 @@ def test_t0_without_diffusion_is_the_pointwise_closed_form(pkg, kind, nlat, cell
     assert err <= 1e-13, err
     assert (want > par["Tm"]).any() and (want < par["Tm"]).any() and cnt["cap_hits"] == 0
     np.testing.assert_array_equal(Ti[ice], np.minimum(T0, par["Tm"])[ice])    # ice_temp, zeroref!: src/miz.jl:31,65-66
+
+
+@pytest.mark.parametrize("nlat", [256, 1024])
+def test_classic_step_follows_the_analytic_mode_recurrence(pkg, nlat, cells):
+    """The classic model on open water without insolation is linear (tests/test_analytic_solutions.py): the P_n
+    amplitudes of E/cw and Tg follow e' = e + dt ((cg/tau) g - M e)/cw, g' = (g + (dt/tau) e')/(1 + dt/tau + n(n+1) dt D/cg).
+    200 steps on the HIP path (forward Euler for E, implicit ghost-layer solve by partition + cyclic reduction)
+    against that recurrence: error x nlat^2 = 0.167, get_diffop's second-order error — no oracle involved."""
+    from test_analytic_solutions import classic_setup
+    st, par, exact = classic_setup(pkg, nlat, 2000)
+    amp = np.array([1.0, 3.0])
+    T, G = exact(0, amp)
+    with make_engine(pkg, "Classic", st, par, 2) as eng:
+        eng.set_state(dict(E=par["cw"] * T, Tg=G))
+        eng.set_time_table(st.t)
+        eng.run(0, 200)
+        got = eng.get_state(("E", "Tg", "T", "h"))
+    assert (got["E"] > 0).all() and not got["h"].any()
+    Tn, Gn = exact(200, amp)
+    err = max(np.max(np.abs(got["E"] / par["cw"] - Tn) / amp[:, None]), np.max(np.abs(got["Tg"] - Gn) / amp[:, None])) * nlat**2
+    record_error(f"classic analytic mode recurrence, {nlat} cells, 200 steps: error x nlat^2", "E/cw, Tg", float(err), 0.18)
+    assert 0.15 < err < 0.18, err
