@@ -227,18 +227,20 @@ def main():
     ev_ms = statistics.median(blocks_ev)
     year_end_ms = None
     if integrate:
-        # Every timed block ends a `year`: ten finish-mean launches and the copy of ten mean fields to
-        # the host.  In the workload's real year (nt = 65,536 steps) that happens once per 65,536 steps;
-        # here once per --steps steps.  Measured separately — years of ONE step — and reported beside
-        # the block time, which includes it.
-        one = []
+        # Every timed block is one ebm_integrate call that ends a `year`: besides its --steps step launches it
+        # allocates and clears the sum buffers, runs ten finish-mean launches and copies ten mean fields to the
+        # host.  In the workload's real year (nt = 65,536 steps) that happens once per 65,536 steps; here once per
+        # --steps steps.  Separated by a second measurement: blocks of 2 x --steps steps cost one more set of step
+        # launches and the same per-call work, so the difference is the steps alone.
+        two = []
         for _ in range(3):
             eng.sync()
             t0 = time.perf_counter()
-            advance(1)
+            advance(2 * args.steps)
             eng.sync()
-            one.append((time.perf_counter() - t0) * 1e3)
-        year_end_ms = max(0.0, statistics.median(one) - elapsed * 1e3 / args.steps)
+            two.append((time.perf_counter() - t0) * 1e3)
+        per_step_ms = max((statistics.median(two) - elapsed * 1e3) / args.steps, 1e-9)
+        year_end_ms = max(0.0, elapsed * 1e3 - per_step_ms * args.steps)
 
     # ---- after the timed region: diagnostics of the state that was timed, CPU baseline --------------
     cpu = None
@@ -299,9 +301,10 @@ def main():
         "preroll_steps": preroll,
         **({"year_end_ms": year_end_ms,
             "ms_per_step_excluding_year_end": (elapsed * 1e3 - year_end_ms) / args.steps,
-            "year_end_note": "each timed block closes a year (10 finish-mean launches + 10 mean fields copied to "
-                             "pageable host memory); value / ms_per_step INCLUDE it once per --steps steps, the "
-                             "workload's own year has 65,536 steps"} if integrate else {}),
+            "year_end_note": "each timed block is one ebm_integrate call closing a year (buffer set-up, 10 finish-mean "
+                             "launches, 10 mean fields copied to pageable host memory); value / ms_per_step INCLUDE that "
+                             "once per --steps steps, the workload's own year has 65,536 steps; separated by timing "
+                             "blocks of 2 x --steps steps as well (the difference is --steps step launches)"} if integrate else {}),
         "config": {
             "workload": f"{name}: {model} model, {nlat} lat x {ncol} meridians per GPU, "
                         f"{kind} grid, nt={nt}, {args.spinup} spin-up steps from zero state, "
