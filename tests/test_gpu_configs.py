@@ -7,6 +7,8 @@ real processes driving the HIP library.
   configs[4]  256-member ensemble of the 1024 x 512 MIZ model,
               32 members per GPU: this GPU's share                    test_config5_per_gpu_share
   SURVEY 8(e) two ranks, each its block of columns, gather to rank 0  test_two_process_sharded_engine
+  configs[3], [4], [2] at full size, every cell against an analytic
+              solution of the model equations (no oracle involved)    test_full_size_*_in_every_cell
 (configs[0], [1] and [3] are in test_gpu_parity.py: golden trajectory, 1440-band sizes case,
 test_full_size_4096x2048_properties.)
 """
@@ -171,3 +173,45 @@ def test_plain_c_caller_of_the_abi(pkg):
         T, phi = eng.get_field("T")[0], eng.get_field("phi")[0]
     assert np.array_equal(vals[:, 0], T, equal_nan=True) and np.array_equal(vals[:, 1], phi, equal_nan=True)
     assert np.any(phi > 0)
+
+
+# ---- every cell of the full-size configurations against an analytic solution -------------------------------------
+# (tests/test_analytic_solutions.py: on open water without insolation a step multiplies the even Legendre modes of T by
+# known factors; the problem is linear, so each column carries its own amplitude and every one of them must come out)
+@pytest.mark.parametrize("name,kind,nlat,ncol,nt,nsteps,limit", [
+    ("cfg4 4096 x 2048", "sin", 4096, 2048, 8388608, 2000, 0.002),          # 2000 steps at a quarter of the explicit limit
+    ("cfg5 share 1024 x 16384", "sin", 1024, 16384, 524288, 500, 0.006),
+])
+def test_full_size_miz_matches_the_analytic_decay_in_every_cell(pkg, name, kind, nlat, ncol, nt, nsteps, limit):
+    from test_analytic_solutions import legendre_setup
+    st, par, exact = legendre_setup(pkg, kind, nlat, nt)
+    amp = 0.25 + 2.0 * np.arange(ncol) / ncol
+    with pkg.Engine("MIZ", st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval), st.dt, ncol, device=0) as eng:
+        eng.set_field("Ew", par["cw"] * exact(0, amp))
+        eng.set_time_table(st.t)
+        eng.run(0, nsteps)
+        Ew, phi, Ei = eng.get_field("Ew"), eng.get_field("phi"), eng.get_field("Ei")
+        cnt = eng.counters()
+    assert not phi.any() and not Ei.any() and cnt["cap_hits"] == 0    # open water throughout
+    err = np.max(np.abs(Ew / par["cw"] - exact(nsteps, amp)) / amp[:, None], axis=1) * nlat**2
+    record_error(f"{name}: analytic Legendre decay in every cell, {nsteps} steps: error x nlat^2", "Ew/cw", float(err.max()), limit)
+    assert err.max() < limit and err.min() > 0.25 * err.max(), (err.min(), err.max())
+
+
+def test_full_size_classic_matches_the_analytic_recurrence_in_every_cell(pkg):
+    """cfg3 at 1024 x 512: the linear open-water recurrence of the classic model, one amplitude per meridian."""
+    from test_analytic_solutions import classic_setup
+    nlat, ncol = 1024, 512
+    st, par, exact = classic_setup(pkg, nlat, 2000)
+    amp = 0.25 + 2.0 * np.arange(ncol) / ncol
+    T, G = exact(0, amp)
+    with pkg.Engine("Classic", st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval), st.dt, ncol, device=0) as eng:
+        eng.set_state(dict(E=par["cw"] * T, Tg=G))
+        eng.set_time_table(st.t)
+        eng.run(0, 200)
+        got = eng.get_state(("E", "Tg", "h"))
+    assert (got["E"] > 0).all() and not got["h"].any()
+    Tn, Gn = exact(200, amp)
+    err = np.maximum(np.max(np.abs(got["E"] / par["cw"] - Tn), axis=1), np.max(np.abs(got["Tg"] - Gn), axis=1)) / amp * nlat**2
+    record_error("cfg3 1024 x 512: analytic mode recurrence in every cell, 200 steps: error x nlat^2", "E/cw, Tg", float(err.max()), 0.18)
+    assert 0.15 < err.min() and err.max() < 0.18, (err.min(), err.max())
