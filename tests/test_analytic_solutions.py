@@ -111,3 +111,43 @@ def test_restated_classic_step_follows_the_analytic_mode_recurrence(oracle, cora
     Tn, Gn = exact(n)
     err = max(np.max(np.abs(s["E"][0] / par["cw"] - Tn)), np.max(np.abs(s["Tg"][0] - Gn))) * nlat**2
     assert 0.15 < err < 0.18, err                                    # measured 0.164 (64), 0.167 (256)
+
+
+# ---- full ice cover, no diffusion, no insolation: every cell is its own scalar recurrence ---------------------------
+# phi = 1, Ew = 0, D = 0 (par), S = 0, Tm = 0: the surface balance gives T0 = Ti = (-A + f)/(k/h + B) < 0; the ice sees
+# Fvi = -A - B T0 + Fb + f; there is no open water (Tw = 0, wlat = 0, no lateral melt, no new ice, Ql = 0), so per step
+#     h' = h - dt Fvi/Lf         (thickness, src/miz.jl:179-181)
+#     Ei' = Ei + dt Fvi          (= -Lf h': the ice stays compact, phi' = 1)
+#     D' = min(Dmax, D + dt (kappa alpha/4) D^3)       (welding only, src/miz.jl:140-146,175-178)
+# — Stefan growth and floe welding, each cell with its own h0 and D0.
+def compact_ice_recurrence(par, dt, h, D, f, nsteps):
+    h, D = h.copy(), D.copy()
+    for _ in range(nsteps):
+        T0 = par["Tm"] + (-par["A"] + f) / (par["k"] / h + par["B"])
+        Fvi = -par["A"] - par["B"] * (T0 - par["Tm"]) + par["Fb"] + f
+        Dold = D
+        D = np.minimum(par["Dmax"], D + dt * (par["kappa"] * par["alpha"] / 4.0) * D**3)
+        h = h - dt * Fvi / par["Lf"]
+    return h, D, T0, Dold                                            # T0 and Dold: what the last step saw (diagnostics Ti, n)
+
+
+def compact_ice_setup(o, nlat, ncol=1):
+    st = o.SpaceTime("sin", nlat, 2000, 1)
+    par = dict(o.default_parameters("MIZ"))
+    par.update(S0=0.0, S1=0.0, S2=0.0, D=0.0, kappa=0.02)            # welding slowed down: at the default rate compact ice
+    rng = np.random.default_rng(nlat)                                # reaches Dmax within two steps
+    h0, D0 = rng.uniform(0.3, 4.0, (ncol, nlat)), rng.uniform(1.0, 150.0, (ncol, nlat))
+    state = {"h": h0.copy(), "D": D0.copy(), "phi": np.ones((ncol, nlat)), "Ei": -par["Lf"] * h0, "Ew": np.zeros((ncol, nlat)),
+             "T0": np.zeros((ncol, nlat))}
+    return st, par, state, h0, D0
+
+
+def test_restated_ice_growth_and_welding_follow_the_scalar_recurrence(oracle, coracle):
+    st, par, state, h0, D0 = compact_ice_setup(oracle, 180)
+    n = 100
+    with np.errstate(all="ignore"):
+        diag, _ = coracle.miz_run(1, st.x, par, st.dt, np.ones(n), np.zeros(n), None, state)
+    h, D, T0, _ = compact_ice_recurrence(par, st.dt, h0, D0, 0.0, n)
+    assert np.max(np.abs(state["h"] / h - 1)) < 1e-13 and np.max(np.abs(state["D"] / D - 1)) < 1e-13
+    assert np.max(np.abs(state["Ei"] / (-par["Lf"] * h) - 1)) < 1e-13 and np.max(np.abs(state["phi"] - 1)) < 1e-13
+    assert np.max(np.abs(diag["Ti"] / T0 - 1)) < 1e-13 and (h > h0).all() and (D > D0).all() and (D < par["Dmax"]).any()

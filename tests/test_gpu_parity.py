@@ -936,3 +936,31 @@ def test_classic_step_follows_the_analytic_mode_recurrence(pkg, nlat, cells):
     err = max(np.max(np.abs(got["E"] / par["cw"] - Tn) / amp[:, None]), np.max(np.abs(got["Tg"] - Gn) / amp[:, None])) * nlat**2
     record_error(f"classic analytic mode recurrence, {nlat} cells, 200 steps: error x nlat^2", "E/cw, Tg", float(err), 0.18)
     assert 0.15 < err < 0.18, err
+
+
+@pytest.mark.parametrize("nlat", [180, 1000, 4096])
+def test_compact_ice_growth_and_welding_follow_the_scalar_recurrence(pkg, nlat, cells):
+    """Full ice cover, D = 0, no insolation (tests/test_analytic_solutions.py): every cell is its own scalar recurrence —
+    T0 = (-A + f)/(k/h + B), h' = h - dt Fvi/Lf with Fvi = -A - B T0 + Fb + f, Ei' = -Lf h', phi' = 1,
+    D' = min(Dmax, D + dt (kappa alpha/4) D^3): Stefan growth and floe welding, 100 steps on the HIP path against a
+    ten-line NumPy loop of those formulas; two columns with different forcing.  No oracle involved."""
+    if cells == 2 and nlat > 1536:
+        pytest.skip("two cells per thread exist up to 1536-cell meridians")
+    from test_analytic_solutions import compact_ice_setup, compact_ice_recurrence
+    st, par, state, h0, D0 = compact_ice_setup(pkg, nlat, 2)
+    fcol = np.array([0.0, -25.0])
+    with make_engine(pkg, "MIZ", st, par, 2) as eng:
+        eng.set_state(state)
+        eng.set_column_forcing(fcol)
+        eng.set_time_table(st.t)
+        eng.run(0, 100, None, True)
+        got = eng.get_state(ALL)
+    worst = 0.0
+    for c in range(2):
+        h, D, T0, Dold = compact_ice_recurrence(par, st.dt, h0[c], D0[c], fcol[c], 100)
+        for name, want in (("h", h), ("D", D), ("Ei", -par["Lf"] * h), ("phi", np.ones(nlat)), ("Ti", T0), ("T0", T0),
+                           ("T", T0), ("E", -par["Lf"] * h), ("n", 1.0 / (par["alpha"] * Dold**2))):     # n: src/miz.jl:83-87, from the floe size before the step
+            worst = max(worst, float(np.max(np.abs(got[name][c] / want - 1.0))))
+        assert (got["Ew"][c] == 0.0).all()
+    record_error(f"compact-ice scalar recurrence, {nlat} cells, 100 steps", "h, D, Ei, phi, Ti, T0, T, E, n", worst, 1e-12)
+    assert worst < 1e-12, worst
