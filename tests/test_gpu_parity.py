@@ -964,3 +964,43 @@ def test_compact_ice_growth_and_welding_follow_the_scalar_recurrence(pkg, nlat, 
         assert (got["Ew"][c] == 0.0).all()
     record_error(f"compact-ice scalar recurrence, {nlat} cells, 100 steps", "h, D, Ei, phi, Ti, T0, T, E, n", worst, 1e-12)
     assert worst < 1e-12, worst
+
+
+def test_custom_grid_function(pkg, coracle, cells):
+    """SpaceTime{F} with a user's own F (src/infrastructure.jl:109-141 takes any function of the uniform coordinate):
+    x = (u + u^2)/2 on u in (0, 1), 250 cells.  Any F but identity goes through the non-uniform stencil
+    (src/infrastructure.jl:505-526) with the x it produced: 30 steps against the oracle from a spun-up state, and the
+    analytic Legendre decay (tests/test_analytic_solutions.py) on this grid too."""
+    F = lambda u: (u + u * u) / 2.0
+    nlat, nt = 250, 40000
+    st = pkg.SpaceTime(F, nlat, nt, 1, urange=(0.0, 1.0))
+    assert st.grid_kind == "nonuniform" and 0 < st.x[0] < st.x[-1] < 1
+    par = pkg.default_parameters("MIZ")
+    fcol = np.array([0.0, 1.5])
+    ct = ctab(pkg, st)
+    state = {k: np.zeros((2, nlat)) for k in PROG + ("T0",)}
+    coracle.miz_run(1, st.x, dict(par), st.dt, ct[:60], np.zeros(60), fcol, state)
+    with make_engine(pkg, "MIZ", st, par, 2) as eng:
+        eng.set_state(state)
+        eng.set_column_forcing(fcol)
+        eng.set_time_table(st.t)
+        eng.run(60, 30)
+        got = eng.get_state(ALL)
+    diag, _ = coracle.miz_run(1, st.x, dict(par), st.dt, ct[60:90], np.zeros(30), fcol, state)
+    check_all(got, dict(state, **diag), 3e-12, what="custom grid x=(u+u^2)/2, 250 cells, 30 steps")   # measured 2.9e-13
+    assert (got["phi"] > 0).any() and (got["phi"] == 0).any()
+    # the analytic solution on the same grid
+    p2 = dict(par, S0=0.0, S1=0.0, S2=0.0, A=0.0, Fb=0.0)
+    x = st.x
+    P2, P4 = (3 * x**2 - 1) / 2, (35 * x**4 - 30 * x**2 + 3) / 8
+    lam, beta = st.dt * p2["D"] / p2["cw"], st.dt * p2["B"] / p2["cw"]
+    g = [1 - m * lam - beta for m in (0, 6, 20)]
+    n = 4000
+    with make_engine(pkg, "MIZ", st, p2, 1) as eng:
+        eng.set_field("Ew", (p2["cw"] * (10.0 + P2 + 0.5 * P4))[None])
+        eng.set_time_table(st.t)
+        eng.run(0, n)
+        T = eng.get_field("Ew")[0] / p2["cw"]
+    err = float(np.max(np.abs(T - (10.0 * g[0]**n + P2 * g[1]**n + 0.5 * P4 * g[2]**n)))) * nlat**2
+    record_error("analytic Legendre decay on the custom grid, 250 cells, 4000 steps: error x nlat^2", "Ew/cw", err, 0.5)
+    assert err < 0.5, err
