@@ -1004,3 +1004,76 @@ def test_custom_grid_function(pkg, coracle, cells):
     err = float(np.max(np.abs(T - (10.0 * g[0]**n + P2 * g[1]**n + 0.5 * P4 * g[2]**n)))) * nlat**2
     record_error("analytic Legendre decay on the custom grid, 250 cells, 4000 steps: error x nlat^2", "Ew/cw", err, 0.5)
     assert err < 0.5, err
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_integrate_randomized_surface(pkg, oracle, seed):
+    """Seeded fuzz of integrate / savesol! (src/infrastructure.jl:549-591, 615-636): random model, grid, length, steps per
+    year, duration, lastonly, winter / summer indices — including a season ON the last step of the year (then no annual
+    mean is taken: the `elif` chain of savesol!) and winter == summer — and a ramping or constant Forcing; every entry of
+    raw, seasonal.winter / summer / avg and ts against the oracle's integrate."""
+    rng = np.random.default_rng(4242 + seed)
+    model = "Classic" if seed % 4 == 3 else "MIZ"
+    kind = "identity" if (model == "Classic" or seed % 2) else "sin"
+    # short runs on short meridians: savesol!'s bookkeeping does not depend on the size, and over thousands of steps
+    # the model itself amplifies rounding differences into ice-edge flips (DESIGN.md, "Sensitivity")
+    nlat = int(rng.choice([2, 5, 9, 16]))
+    nt = int(rng.choice([40, 64, 100]))                              # stable: nt >= 0.13 nlat^2
+    dur = int(rng.integers(1, 4))
+    lastonly = bool(rng.integers(0, 2))
+    w_inx = int(rng.integers(1, nt + 1))
+    s_inx = nt if seed == 1 else (w_inx if seed == 2 else int(rng.integers(1, nt + 1)))
+    kw = dict(winter=(w_inx - 0.25) / nt, summer=(s_inx - 0.25) / nt)
+    st, ost = pkg.SpaceTime(kind, nlat, nt, dur, **kw), oracle.SpaceTime(kind, nlat, nt, dur, **kw)
+    assert (st.winter.inx, st.summer.inx) == (w_inx, s_inx) == (ost.winter_inx, ost.summer_inx)
+    fargs = (0.5,) if seed % 3 == 0 else (0.0, 2.0, 0.0, (1, 0), (2.0, -2.0))
+    forcing, oforcing = pkg.Forcing(*fargs), oracle.Forcing(*fargs)
+    par = pkg.default_parameters(model)
+    if model == "MIZ":
+        init = {k: np.zeros(nlat) for k in PROG}
+        names = oracle.MIZ_SOLVARS
+    else:
+        Ts = 30.0 - 45.0 * st.x ** 2
+        init = dict(E=np.where(Ts >= 0, par["cw"] * Ts, par["Lf"] * Ts / 7.5), Tg=Ts.copy())
+        names = oracle.CLASSIC_SOLVARS
+    # Both forms of the run on the GPU, and the oracle's.  Values are compared with the oracle over the first 30 steps
+    # only: at 40 ... 100 steps per year both models amplify rounding into regime flips within a few hundred steps
+    # (the fp64 oracle is 3e-6 from its own 80-bit build after 192 classic steps of this kind) — what is fuzzed here
+    # is savesol!'s bookkeeping, which is then checked EXACTLY, by identities between the outputs.
+    full = pkg.integrate(model, st, forcing, par, pkg.Collection(init), lastonly=False)
+    last = pkg.integrate(model, st, forcing, par, pkg.Collection(init), lastonly=True)
+    with np.errstate(all="ignore"):
+        ref = oracle.integrate(model, ost, oforcing, dict(par), {k: v.copy() for k, v in init.items()}, lastonly=lastonly)
+    sols = last if lastonly else full
+    assert np.array_equal(sols.ts, ref.ts) and len(full.ts) == nt * dur and len(last.ts) == nt
+    worst = 0.0
+    for v in names:
+        raw = full.raw[v]
+        assert raw.shape == (nt * dur, nlat) and last.raw[v].shape == (nt, nlat)
+        worst = max(worst, scaled_err(raw[:30], np.stack([np.asarray(r) for r in
+                    oracle.integrate(model, ost, oforcing, dict(par), {k: w.copy() for k, w in init.items()}, lastonly=False).raw[v][:30]])))
+        assert np.array_equal(last.raw[v], raw[-nt:], equal_nan=True), v          # lastonly: the last year's snapshots
+        for y in range(dur):
+            yr = raw[y * nt:(y + 1) * nt]
+            for got_l, got_f, want, inx in ((last.seasonal.winter[v], full.seasonal.winter[v], ref.winter[v], w_inx),
+                                            (last.seasonal.summer[v], full.seasonal.summer[v], ref.summer[v], s_inx)):
+                assert np.array_equal(got_l[y], got_f[y], equal_nan=True), (v, y)
+                if want[y] is None:                                  # never written by savesol! (winter == summer: the elif)
+                    assert np.isnan(got_f[y]).all() or not got_f[y].any(), (v, y)
+                else:
+                    assert np.array_equal(got_f[y], yr[inx - 1], equal_nan=True), (v, y)
+            assert np.array_equal(last.seasonal.avg[v][y], full.seasonal.avg[v][y], equal_nan=True), (v, y)
+            if ref.avg[v][y] is None:                                # a season ON the last step of the year: no mean
+                assert np.isnan(full.seasonal.avg[v][y]).all() or not full.seasonal.avg[v][y].any(), (v, y)
+            else:
+                acc = np.zeros(nlat)
+                with np.errstate(all="ignore"):
+                    for row in yr:
+                        acc = acc + row
+                    assert np.array_equal(full.seasonal.avg[v][y], acc / nt, equal_nan=True), (v, y)
+    record_error(f"integrate fuzz seed {seed}: {model} {kind} {nlat} nt={nt} dur={dur} lastonly={lastonly} w={w_inx} s={s_inx}, first 30 steps",
+                 "raw", worst, 1e-9)
+    # measured: <= 2.2e-13 for the MIZ seeds; 1.0e-10 for seed 3 (classic at 64 steps per year: at step 21 a cell changes
+    # regime and every fp64 path jumps by x20 together — there the fp64 oracle is 3.6e-11 from its own 80-bit build and
+    # the GPU 6.4e-11, tests/tools/classic_growth.py)
+    assert worst <= 1e-9, worst
