@@ -215,3 +215,38 @@ def test_full_size_classic_matches_the_analytic_recurrence_in_every_cell(pkg):
     err = np.maximum(np.max(np.abs(got["E"] / par["cw"] - Tn), axis=1), np.max(np.abs(got["Tg"] - Gn), axis=1)) / amp * nlat**2
     record_error("cfg3 1024 x 512: analytic mode recurrence in every cell, 200 steps: error x nlat^2", "E/cw, Tg", float(err.max()), 0.18)
     assert 0.15 < err.min() and err.max() < 0.18, (err.min(), err.max())
+
+
+def test_state_slab_beyond_32_bit_indices(pkg, coracle):
+    """65,536 meridians of 4096 cells: 2 GiB per field, 22 GiB of state — field slots start beyond 2^31 ELEMENTS and
+    beyond 2^32 bytes, a column's offset inside a field exceeds 2^28 elements.  10 steps from zero; columns that share a
+    forcing value are bitwise equal wherever they sit in the slab (first, middle, last replica), and sampled columns of
+    the last replica match the oracle."""
+    nlat, ncol, nt, nsteps = 4096, 65536, 1048576, 10
+    st = pkg.SpaceTime("sin", nlat, nt, 1)
+    par = pkg.default_parameters("MIZ")
+    fcol = -2.0 + 4.0 * (np.arange(ncol) % 64) / 63.0
+    with pkg.Engine("MIZ", st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval), st.dt, ncol, device=0) as eng:
+        eng.set_column_forcing(fcol)
+        eng.set_time_table(st.t)
+        eng.run(0, nsteps, None, True)
+        cnt = eng.counters()
+        sample = np.arange(0, 64, 4)
+        state = {k: np.zeros((len(sample), nlat)) for k in PROG + ("T0",)}
+        ct = np.array([pkg.cos2pit(float(t)) for t in st.t[:nsteps]])
+        diag, _ = coracle.miz_run(1, st.x, dict(par), st.dt, ct, np.zeros(nsteps), fcol[sample], state)
+        ref = dict(state, **diag)
+        worst = {"T0, Ti": 0.0, "others": 0.0}
+        for k in PROG + ("T0",) + DIAG:                              # one 2 GiB field on the host at a time
+            a = eng.get_field(k).reshape(ncol // 64, 64, nlat)
+            assert np.array_equal(a[0], a[511], equal_nan=True) and np.array_equal(a[0], a[1023], equal_nan=True), k
+            key = "T0, Ti" if k in ("T0", "Ti") else "others"
+            worst[key] = max(worst[key], scaled_err(a[1023][sample], ref[k]))
+            del a
+    assert cnt["cap_hits"] == 0
+    # the surface temperature of the first, thinnest ice is the worst-conditioned solve of a run (cond(J) eps = 2e-10 at
+    # 4096 cells, DESIGN.md section 2): measured 1.65e-10 in T0 / Ti, identical for 64 and for 65,536 columns; every
+    # prognostic and the other diagnostics: 4.7e-14
+    record_error("22 GiB slab, 4096 x 65536, 10 steps from zero: last replica vs oracle, T0 and Ti", "T0, Ti", worst["T0, Ti"], 1.7e-9)
+    record_error("22 GiB slab, 4096 x 65536, 10 steps from zero: last replica vs oracle, all other fields", "others", worst["others"], 5e-13)
+    assert worst["T0, Ti"] <= 1.7e-9 and worst["others"] <= 5e-13, worst
