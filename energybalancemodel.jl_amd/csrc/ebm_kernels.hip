@@ -20,12 +20,12 @@
 //   miz_step_kernel<C, GRID, OUT, T, IMEX>   one step per launch; OUT: state only / + diagnostics / savesol! from
 //                                       registers (annual-mean sums, raw snapshots); IMEX: the implicit-diffusion
 //                                       extension (one more tridiagonal solve per step, see include/ebm_hip.h)
-//   miz_fused_kernel<C, GRID, T>        K steps per launch, the whole state in registers (<= 512 threads)
+//   miz_fused_kernel<C, GRID, T>        K steps per launch, the whole state in registers (<= 512 threads; 768 with C = 2)
 //   classic_step_kernel<C, MODE>        WE15 model: single step / savesol! / K steps per launch
 //   diffusion_kernel<GRID>              the diffusion operator on its own (ebm_diffusion)
 //   finish_mean, hemispheric_mean, mask_from_t0, derive_params, divide: small helpers
 // C = cells per thread (4; 2 for a few short meridians), GRID = 0 identity / 1 any other grid, T =
-// workgroup size as a compile-time constant.  Every one of the 285 instantiations uses 0 bytes of scratch
+// workgroup size as a compile-time constant.  Every one of the 293 instantiations uses 0 bytes of scratch
 // (tests/tools/resource_usage.py).
 //
 // Arithmetic policy.  Everything outside the tridiagonal solves is a bit-exact restatement of
@@ -939,7 +939,8 @@ __global__ void __launch_bounds__(1024) miz_step_kernel(const StepArgs a) {
 
 // Fused-K MIZ stepping for meridians of up to 4*kFusedRegThreads cells: a.nfused steps in one launch
 // with the whole state (5 prognostics, the active set, the per-latitude tables) in registers between
-// steps — 256 VGPRs per lane at <= 512 threads — and LDS used only by the solve and the halo
+// steps — 256 VGPRs per lane at <= 512 threads with four cells per thread, 166 at 768 threads with two
+// (1025 ... 1536-cell meridians) — and LDS used only by the solve and the halo
 // exchanges.  Global memory is touched at the start (state in), at the end (state out, diagnostics of
 // the last step if write_diag) and by the scalar loads of the per-step table.  Every step performs the
 // operations of miz_step_kernel in the same order on the same values: bit-identical results
