@@ -250,3 +250,57 @@ def test_state_slab_beyond_32_bit_indices(pkg, coracle):
     record_error("22 GiB slab, 4096 x 65536, 10 steps from zero: last replica vs oracle, T0 and Ti", "T0, Ti", worst["T0, Ti"], 1.7e-9)
     record_error("22 GiB slab, 4096 x 65536, 10 steps from zero: last replica vs oracle, all other fields", "others", worst["others"], 5e-13)
     assert worst["T0, Ti"] <= 1.7e-9 and worst["others"] <= 5e-13, worst
+
+
+def test_handles_from_concurrent_host_threads(pkg):
+    """SURVEY 8(b), threading: the reference keeps its warm start and caches in module-level state and is not re-entrant
+    (src/miz.jl:47, src/infrastructure.jl:500-520); here everything is confined to the handle, each handle has its own
+    stream, and the error string is thread-local.  Six host threads — MIZ on both grids, the classic model, the
+    extension, fused and per-step, an `integrate` — each create, drive and destroy their own handle at the same time
+    (ctypes releases the GIL across the calls); every result is bitwise what the same job gives when run alone, and a
+    failing call in one thread leaves the others' error state untouched."""
+    import threading
+
+    def job(i):
+        model = ("MIZ", "MIZ", "Classic", "MIZ_IMEX", "MIZ", "MIZ")[i]
+        kind = ("sin", "identity", "identity", "sin", "sin", "identity")[i]
+        nlat, ncol = (180, 1000, 512, 1024, 333, 90)[i], (3, 2, 8, 2, 5, 1)[i]
+        nt = (2000, 262144, 2000, 2000, 16384, 500)[i]
+        st = pkg.SpaceTime(kind, nlat, nt, 1)
+        par = pkg.default_parameters("MIZ" if model.startswith("MIZ") else model)
+        with pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval), st.dt, ncol, device=0) as eng:
+            eng.set_column_forcing(np.linspace(-1.0, 1.0, ncol))
+            eng.set_time_table(st.t)
+            if model == "Classic":
+                Ts = 30.0 - 45.0 * st.x ** 2
+                eng.set_state(dict(E=np.tile(np.where(Ts >= 0, par["cw"] * Ts, par["Lf"] * Ts / 7.5), (ncol, 1)), Tg=np.tile(Ts, (ncol, 1))))
+            if i == 5:
+                out = eng.integrate(nt, 1, None, True, st.winter.inx, st.summer.inx, ("E", "T", "h", "phi"))
+                return {k: v for k, v in out.items() if v is not None}
+            for rep in range(6):
+                eng.run(50 * rep, 50, None, rep == 5, steps_per_launch=(16 if i == 4 else 1))
+            if i == 1:                                               # an error in this thread only
+                try:
+                    eng.get_field("Tg")
+                except pkg.EBMError as e:
+                    assert "not part of this model" in str(e)
+            return eng.get_state()
+
+    alone = [job(i) for i in range(6)]
+    together, errors = [None] * 6, []
+
+    def run(i):
+        try:
+            together[i] = job(i)
+        except Exception as e:                                       # noqa: BLE001 - reported below
+            errors.append((i, repr(e)))
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for i in range(6):
+        assert set(alone[i]) == set(together[i])
+        for k in alone[i]:
+            assert np.array_equal(alone[i][k], together[i][k], equal_nan=True), (i, k)
