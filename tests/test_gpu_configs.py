@@ -304,3 +304,38 @@ def test_handles_from_concurrent_host_threads(pkg):
         assert set(alone[i]) == set(together[i])
         for k in alone[i]:
             assert np.array_equal(alone[i][k], together[i][k], equal_nan=True), (i, k)
+
+
+def test_no_device_memory_is_left_behind(pkg):
+    """Create / step / integrate / hemispheric-mean / destroy cycles of a 64 MiB-per-field handle (both models, the fused
+    path with its device table, graph replay on a small one, an `integrate` whose arguments are refused after its
+    buffers exist).  The first use of each kernel and of the runtime's pools takes ~160 MiB once
+    (tests/tools/leak_probe.py); after one pass over all twenty variants, twenty more cycles leave the device's free
+    memory where it was."""
+    import torch
+
+    def cycle(rep):
+        model = "Classic" if rep % 4 == 3 else "MIZ"
+        small = rep % 5 == 0
+        nlat, ncol = (180, 4) if small else (2048, 4096)
+        st = pkg.SpaceTime("identity" if model == "Classic" else "sin", nlat, 2000 if small else 262144, 1)
+        par = pkg.default_parameters(model)
+        with pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval), st.dt, ncol, device=0) as eng:
+            eng.set_time_table(st.t)
+            eng.run(0, 130 if small else 3, None, True, steps_per_launch=(8 if rep % 2 else 1))
+            eng.hemispheric_mean("T")
+            if small:
+                names = ("E", "T", "h") if model == "Classic" else ("E", "T", "phi")
+                eng.integrate(st.nt, 1, None, True, st.winter.inx, st.summer.inx, names)
+                with pytest.raises(pkg.EBMError):
+                    eng.integrate(st.nt, 1, None, True, st.winter.inx, st.summer.inx, ("E", "E"))
+
+    for rep in range(20):
+        cycle(rep)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for rep in range(20):
+        cycle(rep)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free0 - free1) <= 8 * 2**20, (free0, free1)
