@@ -1,0 +1,55 @@
+"""Mutation check of the GPU test suite: deliberately broken builds of the library must be caught.
+
+    python tests/tools/mutants.py build          (here, CPU: one full build per mutant under build/)
+    bash   tests/tools/mutants_run.sh            (GPU box: the -m gpu suite with -x against every mutant)
+
+Each mutant is ONE small textual change of csrc/ebm_kernels.hip — a sign, a dropped select, a broken halo — of the
+kind a transcription error would be.  The runner records the first test that fails for each; a mutant that the whole
+suite lets pass is a hole in the suite.  Nothing here is product code: the mutants live under build/ only."""
+import os, shutil, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+MUTANTS = [
+    ("flux_metric_sign", "return ieee_div((1.0 - xx * xx) * dT, hi_x - lo_x);", "return ieee_div((1.0 + xx * xx) * dT, hi_x - lo_x);"),
+    ("uniform_stencil_skips_equatorward_neighbour", "y = (k > 0) ? y + g0 * tbm : y;", "y = (k > 1) ? y + g0 * tbm : y;"),
+    ("water_temp_keeps_nan", "return __builtin_isnan(tw) ? 0.0 : tw;", "return tw;"),
+    ("t0_rhs_forcing_sign", "return -((p.ai * S - p.A) + dif + f);", "return -((p.ai * S - p.A) + dif - f);"),
+    ("lead_ring_radius_sign", "const double Dr = Dk + p.two_rl;", "const double Dr = Dk - p.two_rl;"),
+    ("ice_enthalpy_not_clamped", "const double cEi = jl_clamp(rEi, -INFINITY, 0.0);", "const double cEi = rEi;"),
+    ("lateral_growth_guard_inverted", "if (hk == 0.0) lat_grow = 0.0;", "if (hk != 0.0) lat_grow = 0.0;"),
+    ("welding_quadratic", "const double weld = p.c_weld * ph * (Dk * Dk * Dk);", "const double weld = p.c_weld * ph * (Dk * Dk);"),
+    ("concentration_not_capped", "if (phi_n > 1.0) phi_n = 1.0;", ""),
+    ("halo_left_is_own_value", "left = t > 0 ? l : 0.0;", "left = t > 0 ? first : 0.0;"),
+    ("back_substitution_drops_left_interface", "x[i] = __builtin_fma(-cp[i], x[i + 1], __builtin_fma(lp[i], L, dp[i]));",
+     "x[i] = __builtin_fma(-cp[i], x[i + 1], dp[i]);"),
+    # (an EQUIVALENT mutant, kept as a control: with E == +-0 both forms give +-0 — the suite cannot and need not see it)
+    ("classic_zero_enthalpy_is_ice", "const double Tk = bool_mul(ieee_div(Ek, p.cw), Ek >= 0.0)", "const double Tk = bool_mul(ieee_div(Ek, p.cw), Ek > 0.0)"),
+    ("classic_surface_temperature_sign", "const double T0 = ieee_div(Cc, p.M - ieee_div(p.kLf, Ek));", "const double T0 = ieee_div(Cc, p.M + ieee_div(p.kLf, Ek));"),
+]
+
+
+def build(only=None):
+    src = os.path.join(ROOT, "energybalancemodel.jl_amd", "csrc")
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    for name, old, new in MUTANTS:
+        if only and name not in only:
+            continue
+        work = f"/tmp/mutant_{name}"
+        shutil.rmtree(work, ignore_errors=True)
+        os.makedirs(os.path.join(work, "energybalancemodel.jl_amd"))
+        shutil.copytree(src, os.path.join(work, "energybalancemodel.jl_amd", "csrc"), ignore=shutil.ignore_patterns("build"))
+        shutil.copytree(os.path.join(ROOT, "include"), os.path.join(work, "include"))
+        path = os.path.join(work, "energybalancemodel.jl_amd", "csrc", "ebm_kernels.hip")
+        text = open(path).read()
+        assert text.count(old) == 1, (name, text.count(old))
+        open(path, "w").write(text.replace(old, new))
+        out = os.path.join(ROOT, "build", f"libebm_mut_{name}.so")
+        subprocess.check_call(["make", "-j8", "-C", os.path.dirname(path), f"OUT={out}", f"BUILD={work}/obj"], stdout=subprocess.DEVNULL)
+        print("built", out, flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1:2] == ["build"]:
+        build(sys.argv[2:])
+    else:
+        print("\n".join(m[0] for m in MUTANTS))
