@@ -151,3 +151,76 @@ def test_restated_ice_growth_and_welding_follow_the_scalar_recurrence(oracle, co
     assert np.max(np.abs(state["h"] / h - 1)) < 1e-13 and np.max(np.abs(state["D"] / D - 1)) < 1e-13
     assert np.max(np.abs(state["Ei"] / (-par["Lf"] * h) - 1)) < 1e-13 and np.max(np.abs(state["phi"] - 1)) < 1e-13
     assert np.max(np.abs(diag["Ti"] / T0 - 1)) < 1e-13 and (h > h0).all() and (D > D0).all() and (D < par["Dmax"]).any()
+
+
+# ---- melt-through: thin compact ice under strong forcing disappears within one step ------------------------------
+# phi = 1, Ew = 0, D = 0, S = 0, f large: the surface is at the melting point (T0 > Tm, Ti = Tm), Fvi = -A + Fb + f > 0 and
+# rEi = Ei + dt Fvi > 0: redistributeE (src/miz.jl:109-117) clamps the ice enthalpy at zero and hands the surplus to the
+# water.  After the step: Ei = h = D = phi = 0 and Ew = -Lf h0 + dt (-A + Fb + f) exactly — the cell's energy is conserved.
+def melt_through_setup(o, nlat=64, ncol=1):
+    st = o.SpaceTime("sin", nlat, 2000, 1)
+    par = dict(o.default_parameters("MIZ"))
+    par.update(S0=0.0, S1=0.0, S2=0.0, D=0.0)
+    rng = np.random.default_rng(7)
+    h0 = rng.uniform(0.001, 0.02, (ncol, nlat))
+    state = {"h": h0.copy(), "D": np.full((ncol, nlat), 30.0), "phi": np.ones((ncol, nlat)), "Ei": -par["Lf"] * h0,
+             "Ew": np.zeros((ncol, nlat)), "T0": np.zeros((ncol, nlat))}
+    f = 900.0
+    want_Ew = -par["Lf"] * h0 + st.dt * (-par["A"] + par["Fb"] + f)
+    assert (want_Ew > 0).all()
+    return st, par, state, f, want_Ew
+
+
+def test_restated_melt_through_conserves_the_cell_energy(oracle, coracle):
+    st, par, state, f, want_Ew = melt_through_setup(oracle)
+    with np.errstate(all="ignore"):
+        coracle.miz_run(1, st.x, par, st.dt, np.ones(1), np.full(1, f), None, state)
+    for k in ("Ei", "h", "D", "phi"):
+        assert not state[k].any(), k
+    assert np.max(np.abs(state["Ew"] / want_Ew - 1)) < 1e-13
+
+
+# ---- classic model with ice and without diffusion: WE15 eqs (A1)-(A3), (9) cell by cell -----------------------------
+# D = 0 (the ghost-layer system is diagonal), S = 0.  With M = B + cg/tau:
+#     C = (cg/tau) Tg - A + f;  T0 = C/(M - k Lf/E);  T = E/cw (E >= 0), T0 (E < 0, T0 < 0), 0 (E < 0, T0 >= 0: melting)
+#     E' = E + dt (C - M T + Fb)
+#     Tg' = [Tg + (dt/tau) (E'/cw or, on cold ice, (-A + f)/(M - k Lf/E'))] / [1 + dt/tau - (dt/tau)(cg/tau)/(M - k Lf/E') on cold ice]
+#     h' = -E'/Lf (E' < 0)
+# ("cold ice": E' < 0 and the T0 of this step < 0).  Cells start as thick ice, thin ice and open water.
+def classic_ice_recurrence(par, dt, E, Tg, f, nsteps):
+    E, Tg = E.copy(), Tg.copy()
+    cgt, dtt = par["cg"] / par["tau"], dt / par["tau"]
+    M, kLf = par["B"] + cgt, par["k"] * par["Lf"]
+    with np.errstate(all="ignore"):
+        for _ in range(nsteps):
+            C = cgt * Tg - par["A"] + f
+            T0 = C / (M - kLf / E)
+            T = np.where(E >= 0, E / par["cw"], np.where(T0 < 0, T0, 0.0))
+            E = E + dt * (C - M * T + par["Fb"])
+            cold = (E < 0) & (T0 < 0)
+            den = M - kLf / E
+            src = np.where(E >= 0, E / par["cw"], np.where(cold, (-par["A"] + f) / den, 0.0))
+            Tg = (Tg + dtt * src) / (1.0 + dtt - np.where(cold, dtt * cgt / den, 0.0))
+    return E, Tg, T, np.where(E < 0, -E / par["Lf"], 0.0)
+
+
+def classic_ice_setup(o, nlat=96, ncol=1):
+    st = o.SpaceTime("identity", nlat, 2000, 1)
+    par = dict(o.default_parameters("Classic"))
+    par.update(S0=0.0, S1=0.0, S2=0.0, D=0.0)
+    rng = np.random.default_rng(11)
+    E = np.where(rng.random((ncol, nlat)) < 0.6, -par["Lf"] * rng.uniform(0.05, 3.0, (ncol, nlat)), par["cw"] * rng.uniform(0.5, 20.0, (ncol, nlat)))
+    Tg = rng.uniform(-20.0, 25.0, (ncol, nlat))
+    return st, par, E, Tg
+
+
+def test_restated_classic_ice_follows_the_cellwise_recurrence(oracle, coracle):
+    st, par, E0, Tg0 = classic_ice_setup(oracle)
+    n, f = 150, 40.0                                                 # A - f = 153 W/m2 of cooling: open water freezes on the way
+    s = dict(E=E0.copy(), Tg=Tg0.copy())
+    out = coracle.classic_run(st.x, par, st.dt, np.ones(n), np.ones(n), np.full(n, f), None, s)
+    s.update(out)
+    E, Tg, T, h = classic_ice_recurrence(par, st.dt, E0, Tg0, f, n)
+    assert ((E0 > 0) & (E < 0)).any() and (E0 < 0).any()
+    for got, want in ((s["E"], E), (s["Tg"], Tg), (s["T"], T), (s["h"], h)):
+        assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 1e-12

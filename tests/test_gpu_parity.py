@@ -1077,3 +1077,41 @@ def test_integrate_randomized_surface(pkg, oracle, seed):
     # regime and every fp64 path jumps by x20 together — there the fp64 oracle is 3.6e-11 from its own 80-bit build and
     # the GPU 6.4e-11, tests/tools/classic_growth.py)
     assert worst <= 1e-9, worst
+
+
+def test_melt_through_hands_the_surplus_to_the_water(pkg, cells):
+    """Thin compact ice under 900 W/m2 of forcing melts within one step (tests/test_analytic_solutions.py): the ice
+    enthalpy is clamped at zero and the surplus goes to the water (redistributeE, src/miz.jl:109-117) — afterwards
+    Ei = h = D = phi = 0 and Ew = -Lf h0 + dt (-A + Fb + f): the cell's energy, conserved.  No oracle involved."""
+    from test_analytic_solutions import melt_through_setup
+    st, par, state, f, want_Ew = melt_through_setup(pkg, 200, 2)
+    with make_engine(pkg, "MIZ", st, par, 2) as eng:
+        eng.set_state(state)
+        eng.set_time_table(st.t)
+        eng.run(0, 1, np.full(1, f), True)
+        got = eng.get_state(ALL)
+    for k in ("Ei", "h", "D", "phi", "n"):
+        assert not got[k].any() or k == "n", k
+    err = float(np.max(np.abs(got["Ew"] / want_Ew - 1)))
+    record_error("melt-through: Ew = -Lf h0 + dt (-A + Fb + f)", "Ew", err, 1e-13)
+    assert err < 1e-13 and np.isnan(got["Ti"]).all()                 # no ice left: the sentinel of src/miz.jl:193
+
+
+@pytest.mark.parametrize("nlat", [96, 1024])
+def test_classic_ice_follows_the_cellwise_recurrence(pkg, nlat, cells):
+    """The classic model with ice and without diffusion or insolation, cell by cell from WE15 eqs (A1)-(A3), (9)
+    (tests/test_analytic_solutions.py): thick ice, thin ice and open water that freezes on the way, 150 steps on the HIP
+    path against a fifteen-line NumPy loop of those equations.  No oracle involved."""
+    from test_analytic_solutions import classic_ice_setup, classic_ice_recurrence
+    st, par, E0, Tg0 = classic_ice_setup(pkg, nlat, 3)
+    n, f = 150, 40.0
+    with make_engine(pkg, "Classic", st, par, 3) as eng:
+        eng.set_state(dict(E=E0, Tg=Tg0))
+        eng.set_time_table(st.t)
+        eng.run(0, n, np.full(n, f), True)
+        got = eng.get_state(("E", "Tg", "T", "h"))
+    E, Tg, T, h = classic_ice_recurrence(par, st.dt, E0, Tg0, f, n)
+    assert ((E0 > 0) & (E < 0)).any() and (E0 < 0).any()
+    worst = max(float(np.max(np.abs(got[k] - w) / np.maximum(1.0, np.abs(w)))) for k, w in (("E", E), ("Tg", Tg), ("T", T), ("h", h)))
+    record_error(f"classic ice cell-wise recurrence, {nlat} cells, 150 steps", "E, Tg, T, h", worst, 1e-12)
+    assert worst < 1e-12, worst
