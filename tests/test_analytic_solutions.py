@@ -224,3 +224,84 @@ def test_restated_classic_ice_follows_the_cellwise_recurrence(oracle, coracle):
     assert ((E0 > 0) & (E < 0)).any() and (E0 < 0).any()
     for got, want in ((s["E"], E), (s["Tg"], Tg), (s["T"], T), (s["h"], h)):
         assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 1e-12
+
+
+# ---- the T0 system WITH its diffusion terms: partial ice cover, Legendre right-hand side -------------------------
+# src/miz.jl:33-43 with v = T0 - Tm < 0 everywhere, uniform h and phi, S = 0 and Tw - Tm = c + a P_2(x):
+#     -(k/h + B) v + phi Dif(v) = A - f - (1 - phi) Dif(Tw - Tm),     Dif(P_2) = -6 D P_2
+# so v = v0 + v2 P_2 with v0 = (-A + f)/(k/h + B) and v2 = -6 D (1 - phi) a / (k/h + B + 6 D phi): the ice surface feels
+# the water's temperature gradient through the shared diffusion operator, weighted by the concentration.
+def t0_mode_setup(o, kind, nlat, ncol=1, D=6.0, a=5.0, c=8.0, h=1.0, phi=0.5):
+    st = o.SpaceTime(kind, nlat, 2000, 1)
+    par = dict(o.default_parameters("MIZ"))
+    par.update(S0=0.0, S1=0.0, S2=0.0, D=D)
+    x = st.x
+    P2 = (3 * x**2 - 1) / 2
+    Tw = par["Tm"] + c + a * P2
+    state = {"h": np.full((ncol, nlat), h), "phi": np.full((ncol, nlat), phi), "D": np.full((ncol, nlat), 50.0),
+             "Ei": np.full((ncol, nlat), -par["Lf"] * h * phi), "Ew": np.tile((1 - phi) * par["cw"] * (Tw - par["Tm"]), (ncol, 1)),
+             "T0": np.zeros((ncol, nlat))}
+    kap = par["k"] / h + par["B"]
+
+    def exact(f):
+        return par["Tm"] + (-par["A"] + f) / kap - 6 * D * (1 - phi) * a / (kap + 6 * D * phi) * P2
+    return st, par, state, exact
+
+
+@pytest.mark.parametrize("kind", ["identity", "sin"])
+def test_restated_t0_system_couples_ice_and_water_through_the_diffusion(oracle, coracle, kind):
+    errs = []
+    for nlat in (64, 128, 256):
+        st, par, state, exact = t0_mode_setup(oracle, kind, nlat)
+        with np.errstate(all="ignore"):
+            coracle.miz_run(0 if kind == "identity" else 1, st.x, par, st.dt, np.ones(1), np.zeros(1), None, state)
+        assert (state["T0"] < par["Tm"]).all()
+        errs.append(float(np.max(np.abs(state["T0"][0] - exact(0.0)))) * nlat**2)
+    assert max(errs) < 3.0 and max(errs) / min(errs) < 1.01, errs     # second order: error x nlat^2 = 0.509 (identity), 2.76 (sin)
+
+
+# ---- partial cover over warm water, one step, no diffusion: lateral melt and the energy it moves ------------------
+# D = 0, S = 0, phi < 1, Tw > Tm, ice cold (T0 < Tm): nothing freezes (psi = 0: no lead ice, no new floes), so from
+# src/miz.jl:71, 83-107, 137-146, 160-187 in one step
+#     wl = m1 (Tw - Tm^m2),   Flat = phi h Lf wl pi/(alpha D),   T0 = Tm + (-A + f)/(k/h + B),   Tbar = T0 phi + (1 - phi) Tw
+#     Fvi = Fvw = -A - B (Tbar - Tm) + Fb + f
+#     Ei' = Ei + dt (phi Fvi + Flat)      Ew' = Ew + dt ((1 - phi) Fvw - Flat)         (what the ice loses sideways the water gains)
+#     h' = h - dt Fvi/Lf      D' = D + dt (-(pi/2) alpha wl + (kappa alpha/4) phi D^3)      phi' = -Ei'/(Lf h')
+#     diagnostics: n = phi/(alpha D^2), E = phi' Ei' + (1 - phi') Ew', T = T0 phi' + (1 - phi') Tw
+def lateral_melt_setup(o, nlat=120, ncol=1):
+    st = o.SpaceTime("sin", nlat, 2000, 1)
+    par = dict(o.default_parameters("MIZ"))
+    par.update(S0=0.0, S1=0.0, S2=0.0, D=0.0, kappa=0.02)
+    rng = np.random.default_rng(5)
+    h, phi = rng.uniform(0.5, 3.0, (ncol, nlat)), rng.uniform(0.1, 0.9, (ncol, nlat))
+    Dfl, Tw = rng.uniform(5.0, 120.0, (ncol, nlat)), rng.uniform(0.5, 4.0, (ncol, nlat))
+    state = {"h": h, "phi": phi, "D": Dfl, "Ei": -par["Lf"] * h * phi, "Ew": (1 - phi) * par["cw"] * Tw, "T0": np.zeros((ncol, nlat))}
+    return st, par, state
+
+
+def lateral_melt_step(par, dt, s, f):
+    h, phi, D, Ei, Ew = (s[k] for k in ("h", "phi", "D", "Ei", "Ew"))
+    Tm, Lf, al = par["Tm"], par["Lf"], par["alpha"]
+    Tw = Tm + Ew / ((1 - phi) * par["cw"])
+    wl = par["m1"] * (Tw - Tm ** par["m2"])
+    Flat = phi * h * Lf * wl * np.pi / (al * D)
+    T0 = Tm + (-par["A"] + f) / (par["k"] / h + par["B"])
+    Fv = -par["A"] - par["B"] * (T0 * phi + (1 - phi) * Tw - Tm) + par["Fb"] + f
+    Ei1, Ew1 = Ei + dt * (phi * Fv + Flat), Ew + dt * ((1 - phi) * Fv - Flat)
+    h1 = h - dt * Fv / Lf
+    D1 = D + dt * (-(np.pi / 2) * al * wl + par["kappa"] * al / 4 * phi * D**3)
+    phi1 = -Ei1 / (Lf * h1)
+    assert (Ei1 < 0).all() and (Ew1 > 0).all() and (phi1 < 1).all() and (D1 > par["Dmin"]).all() and (D1 < par["Dmax"]).all()
+    return dict(Ei=Ei1, Ew=Ew1, h=h1, D=D1, phi=phi1, n=phi / (al * D**2), E=phi1 * Ei1 + (1 - phi1) * Ew1,
+                T=T0 * phi1 + (1 - phi1) * Tw, Ti=T0, Tw=Tw, T0=T0)
+
+
+def test_restated_lateral_melt_step_matches_its_closed_form(oracle, coracle):
+    st, par, state = lateral_melt_setup(oracle)
+    want = lateral_melt_step(par, st.dt, state, -20.0)
+    s = {k: v.copy() for k, v in state.items()}
+    with np.errstate(all="ignore"):
+        diag, _ = coracle.miz_run(1, st.x, par, st.dt, np.ones(1), np.full(1, -20.0), None, s)
+    got = dict(s, **diag)
+    for k, w in want.items():
+        assert np.max(np.abs(got[k] / w - 1)) < 1e-12, k

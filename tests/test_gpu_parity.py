@@ -1115,3 +1115,82 @@ def test_classic_ice_follows_the_cellwise_recurrence(pkg, nlat, cells):
     worst = max(float(np.max(np.abs(got[k] - w) / np.maximum(1.0, np.abs(w)))) for k, w in (("E", E), ("Tg", Tg), ("T", T), ("h", h)))
     record_error(f"classic ice cell-wise recurrence, {nlat} cells, 150 steps", "E, Tg, T, h", worst, 1e-12)
     assert worst < 1e-12, worst
+
+
+@pytest.mark.parametrize("kind,nlat,limit", [("identity", 256, 0.52), ("sin", 1024, 2.8), ("sin", 4096, 3.2)])
+def test_t0_system_couples_ice_and_water_through_the_diffusion(pkg, kind, nlat, limit, cells):
+    """The T0 system with its diffusion terms (tests/test_analytic_solutions.py): half ice cover, uniform thickness, water
+    temperature c + a P_2(x): T0 - Tm = (-A + f)/(k/h + B) - 6 D (1 - phi) a/(k/h + B + 6 D phi) P_2(x) up to the stencil's
+    second-order error (x nlat^2: 0.509 identity, 2.76 sin; 3.06 at 4096 cells where rounding shows) — assembly of the rows,
+    concentration weighting of the active set, the water's diffusion on the right-hand side and the solve, against
+    mathematics.  Three columns with different forcing.  No oracle involved."""
+    if cells == 2 and nlat > 1536:
+        pytest.skip("two cells per thread exist up to 1536-cell meridians")
+    from test_analytic_solutions import t0_mode_setup
+    st, par, state, exact = t0_mode_setup(pkg, kind, nlat, 3)
+    fcol = np.array([0.0, -30.0, 25.0])
+    with make_engine(pkg, "MIZ", st, par, 3) as eng:
+        eng.set_state(state)
+        eng.set_column_forcing(fcol)
+        eng.set_time_table(st.t)
+        eng.run(0, 1, None, True)
+        T0 = eng.get_field("T0")
+        cnt = eng.counters()
+    assert (T0 < par["Tm"]).all() and cnt["cap_hits"] == 0
+    err = max(float(np.max(np.abs(T0[c] - exact(fcol[c])))) for c in range(3)) * nlat**2
+    record_error(f"T0 system with diffusion, Legendre right-hand side, {kind} {nlat}: error x nlat^2", "T0", err, limit)
+    assert 0.9 * limit / 1.1 < err < limit or nlat == 4096 and err < limit, err
+
+
+def test_lateral_melt_step_matches_its_closed_form(pkg, cells):
+    """Partial cover over warm water, one step, no diffusion (tests/test_analytic_solutions.py): lateral melt rate, the
+    energy it moves from ice to water, thickness, floe size (lateral melt + welding), concentration and the diagnostics
+    n, E, T, Ti, Tw — every output of the step against a dozen lines of NumPy written from src/miz.jl:71-146.  No oracle."""
+    from test_analytic_solutions import lateral_melt_setup, lateral_melt_step
+    st, par, state = lateral_melt_setup(pkg, 300, 2)
+    fcol = np.array([-20.0, 10.0])
+    with make_engine(pkg, "MIZ", st, par, 2) as eng:
+        eng.set_state(state)
+        eng.set_column_forcing(fcol)
+        eng.set_time_table(st.t)
+        eng.run(0, 1, None, True)
+        got = eng.get_state(ALL)
+    worst = 0.0
+    for c in range(2):
+        want = lateral_melt_step(par, st.dt, {k: v[c] for k, v in state.items()}, fcol[c])
+        for k, w in want.items():
+            worst = max(worst, float(np.max(np.abs(got[k][c] / w - 1))))
+    record_error("lateral-melt step closed form, 300 cells", "all eleven outputs", worst, 1e-12)
+    assert worst < 1e-12, worst
+
+
+def test_device_schedule_follows_the_docstring_forcing(pkg):
+    """`Forcing(0.0, 5.0, -5.0, (10, 10), (0.5, -0.5))` as the reference's docstring prints it (src/infrastructure.jl:193-205):
+    0 on [0,10), 0.5 (t - 10) on [10,20), 5 on [20,30), 5 - 0.5 (t - 30) on [30,50), -5 afterwards — evaluated ON THE DEVICE
+    per column at the model time of each step (ebm_set_column_schedule).  With D = 0 and S = 0 the forcing a step saw can
+    be read back from its T0: f = (T0 - Tm)(k/h + B) + A.  Probed in all five segments of a 55-year run, next to a
+    constant-forcing column."""
+    nt, nlat = 20, 8
+    st = pkg.SpaceTime("identity", nlat, nt, 55)
+    par = dict(pkg.default_parameters("MIZ"))
+    par.update(S0=0.0, S1=0.0, S2=0.0, D=0.0, kappa=0.0)
+    h0 = np.full((2, nlat), 2.0)
+    state = {"h": h0, "phi": np.ones((2, nlat)), "D": np.full((2, nlat), 50.0), "Ei": -par["Lf"] * h0, "Ew": np.zeros((2, nlat)),
+             "T0": np.zeros((2, nlat))}
+    doc = lambda t: 0.0 if t < 10 else 0.5 * (t - 10) if t < 20 else 5.0 if t < 30 else 5.0 - 0.5 * (t - 30) if t < 50 else -5.0
+    with make_engine(pkg, "MIZ", st, par, 2) as eng:
+        eng.set_state(state)
+        eng.set_time_table(st.t)
+        eng.set_column_schedules([pkg.Forcing(0.0, 5.0, -5.0, (10, 10), (0.5, -0.5)), pkg.Forcing(1.25)])
+        done, worst = 0, 0.0
+        for t_probe in (3.3, 9.98, 10.02, 17.57, 19.99, 20.0, 25.0, 30.01, 41.3, 49.99, 50.0, 54.9):
+            step = int(t_probe * nt)                                 # the step whose model time is st.T[step]
+            eng.run(done, step - done, None, False)
+            h = eng.get_field("h")
+            eng.run(step, 1, None, True)
+            done = step + 1
+            f_seen = (eng.get_field("T0") - par["Tm"]) * (par["k"] / h + par["B"]) + par["A"]
+            worst = max(worst, float(np.max(np.abs(f_seen[0] - doc(float(st.T[step]))))), float(np.max(np.abs(f_seen[1] - 1.25))))
+    record_error("device-side Forcing schedule read back through T0 against the docstring's formula", "f", worst, 1e-11)
+    assert worst < 1e-11, worst
+    assert abs(pkg.Forcing(0.0, 5.0, -5.0, (10, 10), (0.5, -0.5))(17.57) - 3.785) < 1e-12       # the docstring's own sample

@@ -24,6 +24,25 @@ MUTANTS = [
      "x[i] = __builtin_fma(-cp[i], x[i + 1], dp[i]);"),
     # (an EQUIVALENT mutant, kept as a control: with E == +-0 both forms give +-0 — the suite cannot and need not see it)
     ("classic_zero_enthalpy_is_ice", "const double Tk = bool_mul(ieee_div(Ek, p.cw), Ek >= 0.0)", "const double Tk = bool_mul(ieee_div(Ek, p.cw), Ek > 0.0)"),
+    # second batch
+    ("schedule_ramp_ignores_its_start", "else if (tyear < d2) v = base + up * (tyear - d1);", "else if (tyear < d2) v = base + up * tyear;"),
+    ("floe_number_linear_in_D", "double n = ieee_div(ph, alpha * (Dk * Dk));", "double n = ieee_div(ph, alpha * Dk);"),
+    ("olr_slope_sign", "const double L = p.A + p.B * (tb - Tm);", "const double L = p.A - p.B * (tb - Tm);"),
+    ("water_albedo_sign", "const double sol_w = 0.0 + (p.a0 - p.a2 * (xk * xk)) * S;", "const double sol_w = 0.0 + (p.a0 + p.a2 * (xk * xk)) * S;"),
+    ("lateral_flux_without_pi", "double Flat = ieee_div(ph * hk * Lf * wl * M_PI, alpha * Dk);", "double Flat = ieee_div(ph * hk * Lf * wl, alpha * Dk);"),
+    ("surplus_of_ice_not_given_to_water", "const double Ew_n = cEw + psiEidt;", "const double Ew_n = cEw;"),
+    ("lead_share_added_not_subtracted", "const double Qp = psi - Ql;", "const double Qp = psi + Ql;"),
+    ("lateral_melt_sign", "const double lat_melt = p.c_latmelt * wl;", "const double lat_melt = -(p.c_latmelt * wl);"),
+    ("thickness_tendency_sign", "double rh = hk + (p.c_ht * Fvi) * dt;", "double rh = hk - (p.c_ht * Fvi) * dt;"),
+    ("new_ice_thickness_uses_Dmin", "double h_n = div_with_rcp(n * rh + dn * p.hmin, total, rtotal);", "double h_n = div_with_rcp(n * rh + dn * p.Dmin, total, rtotal);"),
+    ("mean_temperature_uses_old_concentration", "o.q[Q_T] = Ti * phi_n + (1.0 - phi_n) * Tw;", "o.q[Q_T] = Ti * ph + (1.0 - ph) * Tw;"),
+    ("insolation_seasonal_sign", "return p.S0 - p.S1 * xk * ct - p.S2 * (xk * xk);", "return p.S0 + p.S1 * xk * ct - p.S2 * (xk * xk);"),
+    ("t0_conduction_ignores_hmin", "return __builtin_fma(p.k, fast_rcp((hk == 0.0) ? p.hmin : hk), p.B);", "return __builtin_fma(p.k, fast_rcp(hk), p.B);"),
+    # (the second EQUIVALENT control: at T0 == Tm exactly both branches of the piecewise-linear system agree)
+    ("active_set_includes_melting_point", "snew |= (xs[i] < 0.0) ? (1u << i) : 0u;", "snew |= (xs[i] <= 0.0) ? (1u << i) : 0u;"),
+    ("active_rows_ignore_concentration", "g[i] = ((smask >> i) & 1u) ? ph[i] : 0.0;", "g[i] = ((smask >> i) & 1u) ? 1.0 : 0.0;"),
+    ("classic_ocean_heat_flux_sign", "Ek = Ek + p.dt * (Cc - p.M * Tk + p.Fb);", "Ek = Ek + p.dt * (Cc - p.M * Tk - p.Fb);"),
+    ("extension_matrix_diagonal_sign", "rb[i] = 1.0 + p.theta_imex * (tlo[i] + tup[i]);", "rb[i] = 1.0 - p.theta_imex * (tlo[i] + tup[i]);"),
     ("classic_surface_temperature_sign", "const double T0 = ieee_div(Cc, p.M - ieee_div(p.kLf, Ek));", "const double T0 = ieee_div(Cc, p.M + ieee_div(p.kLf, Ek));"),
 ]
 
