@@ -3,7 +3,7 @@
     python tests/tools/mutants.py build          (here, CPU: one full build per mutant under build/)
     bash   tests/tools/mutants_run.sh            (GPU box: the -m gpu suite with -x against every mutant)
 
-Each mutant is ONE small textual change of csrc/ebm_kernels.hip — a sign, a dropped select, a broken halo — of the
+Each mutant is ONE small textual change of csrc/ebm_kernels.hip (or csrc/ebm_runtime.hip) — a sign, a dropped select, a broken halo — of the
 kind a transcription error would be.  The runner records the first test that fails for each; a mutant that the whole
 suite lets pass is a hole in the suite.  Nothing here is product code: the mutants live under build/ only."""
 import os, shutil, subprocess, sys
@@ -43,6 +43,17 @@ MUTANTS = [
     ("active_rows_ignore_concentration", "g[i] = ((smask >> i) & 1u) ? ph[i] : 0.0;", "g[i] = ((smask >> i) & 1u) ? 1.0 : 0.0;"),
     ("classic_ocean_heat_flux_sign", "Ek = Ek + p.dt * (Cc - p.M * Tk + p.Fb);", "Ek = Ek + p.dt * (Cc - p.M * Tk - p.Fb);"),
     ("extension_matrix_diagonal_sign", "rb[i] = 1.0 + p.theta_imex * (tlo[i] + tup[i]);", "rb[i] = 1.0 - p.theta_imex * (tlo[i] + tup[i]);"),
+    # third batch: the host runtime (tables, time bookkeeping, savesol!) and the small kernels; a 4-tuple names the file
+    ("uniform_table_metric_linear", "lam[i - 1] = (1.0 - xb * xb) / (dx * dx);", "lam[i - 1] = (1.0 - xb) / (dx * dx);", "ebm_runtime.hip"),
+    ("polar_ghost_cell_misplaced", "double xp = k < nx - 1 ? x[k + 1] : 2.0 - x[nx - 1];", "double xp = k < nx - 1 ? x[k + 1] : 1.0 - x[nx - 1];", "ebm_runtime.hip"),
+    ("solver_table_uses_wrong_spacing", "double l = p.D * g1[k] / (g3[k] * g4[k]);", "double l = p.D * g1[k] / (g2[k] * g4[k]);", "ebm_runtime.hip"),
+    ("classic_ghost_diagonal_sign", "kdiag[k] = one - (dtD * g1[k]) / p.cg;", "kdiag[k] = one + (dtD * g1[k]) / p.cg;", "ebm_runtime.hip"),
+    ("model_time_at_step_start", "return nt > 0.0 ? (double)(2 * step + 1) / (2.0 * nt) : 0.0;", "return nt > 0.0 ? (double)(2 * step) / (2.0 * nt) : 0.0;", "ebm_runtime.hip"),
+    ("lastonly_keeps_one_step_too_many", "const bool want_raw = stage && (!lastonly || tinx > total - nt);", "const bool want_raw = stage && (!lastonly || tinx >= total - nt);", "ebm_runtime.hip"),
+    ("winter_snapshot_one_step_late", "if (ti == winter_inx) {", "if (ti == winter_inx + 1) {", "ebm_runtime.hip"),
+    ("annual_mean_divides_by_nt_minus_1", "m.x = s.x / nt;", "m.x = s.x / (nt - 1.0);"),
+    ("annual_sum_not_restarted", "z.x = 0.0;", "z.x = s.x;"),
+    ("hemispheric_mean_without_the_half", "terms[i] = ieee_div((v[i] + v[i + 1]) * (x[i + 1] - x[i]), 2.0);", "terms[i] = (v[i] + v[i + 1]) * (x[i + 1] - x[i]);"),
     ("classic_surface_temperature_sign", "const double T0 = ieee_div(Cc, p.M - ieee_div(p.kLf, Ek));", "const double T0 = ieee_div(Cc, p.M + ieee_div(p.kLf, Ek));"),
 ]
 
@@ -50,7 +61,7 @@ MUTANTS = [
 def build(only=None):
     src = os.path.join(ROOT, "energybalancemodel.jl_amd", "csrc")
     os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
-    for name, old, new in MUTANTS:
+    for name, old, new, *where in MUTANTS:
         if only and name not in only:
             continue
         work = f"/tmp/mutant_{name}"
@@ -58,7 +69,7 @@ def build(only=None):
         os.makedirs(os.path.join(work, "energybalancemodel.jl_amd"))
         shutil.copytree(src, os.path.join(work, "energybalancemodel.jl_amd", "csrc"), ignore=shutil.ignore_patterns("build"))
         shutil.copytree(os.path.join(ROOT, "include"), os.path.join(work, "include"))
-        path = os.path.join(work, "energybalancemodel.jl_amd", "csrc", "ebm_kernels.hip")
+        path = os.path.join(work, "energybalancemodel.jl_amd", "csrc", where[0] if where else "ebm_kernels.hip")
         text = open(path).read()
         assert text.count(old) == 1, (name, text.count(old))
         open(path, "w").write(text.replace(old, new))
