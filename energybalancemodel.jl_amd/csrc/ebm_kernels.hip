@@ -1159,7 +1159,9 @@ __global__ void __launch_bounds__(1024) classic_step_kernel(const StepArgs a) {
                                     (int)kp < nlat, (int)kp + 1 < nlat);
             }
         }
-        if (LOOP) __syncthreads();                         // the solve's LDS buffers are reused by the next step
+        // (no barrier between the solves of consecutive steps: after a solve's last barrier the threads only READ P0; the
+        // next solve first writes each thread's own words of P1 — which nobody reads after that last barrier — and passes
+        // a barrier of its own before anything is written to P0)
     }
 }
 

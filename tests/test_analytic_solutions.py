@@ -187,19 +187,24 @@ def test_restated_melt_through_conserves_the_cell_energy(oracle, coracle):
 #     Tg' = [Tg + (dt/tau) (E'/cw or, on cold ice, (-A + f)/(M - k Lf/E'))] / [1 + dt/tau - (dt/tau)(cg/tau)/(M - k Lf/E') on cold ice]
 #     h' = -E'/Lf (E' < 0)
 # ("cold ice": E' < 0 and the T0 of this step < 0).  Cells start as thick ice, thin ice and open water.
-def classic_ice_recurrence(par, dt, E, Tg, f, nsteps):
+def classic_ice_recurrence(par, dt, E, Tg, f, nsteps, x=None, t=None):
+    """x, t given: with insolation S(x, t) = S0 - S2 x^2 - S1 cos(2 pi t) x (WE15 eq. (3)), albedo aw = a0 - a2 x^2 over
+    water and ai over ice (eq. (4)); the ghost layer's ice term takes S at the NEXT time level (src/classic.jl:58-60)."""
     E, Tg = E.copy(), Tg.copy()
     cgt, dtt = par["cg"] / par["tau"], dt / par["tau"]
     M, kLf = par["B"] + cgt, par["k"] * par["Lf"]
+    sun = lambda tt: 0.0 if x is None else par["S0"] - par["S2"] * x**2 - par["S1"] * np.cos(2.0 * np.pi * tt) * x
     with np.errstate(all="ignore"):
-        for _ in range(nsteps):
-            C = cgt * Tg - par["A"] + f
+        for n in range(nsteps):
+            S, Sn = (0.0, 0.0) if x is None else (sun(t[n % len(t)]), sun(t[(n + 1) % len(t)]))
+            alpha = 0.0 if x is None else np.where(E > 0, par["a0"] - par["a2"] * x**2, np.where(E < 0, par["ai"], 0.0))
+            C = alpha * S + cgt * Tg - par["A"] + f
             T0 = C / (M - kLf / E)
             T = np.where(E >= 0, E / par["cw"], np.where(T0 < 0, T0, 0.0))
             E = E + dt * (C - M * T + par["Fb"])
             cold = (E < 0) & (T0 < 0)
             den = M - kLf / E
-            src = np.where(E >= 0, E / par["cw"], np.where(cold, (-par["A"] + f) / den, 0.0))
+            src = np.where(E >= 0, E / par["cw"], np.where(cold, (par["ai"] * Sn - par["A"] + f) / den, 0.0))
             Tg = (Tg + dtt * src) / (1.0 + dtt - np.where(cold, dtt * cgt / den, 0.0))
     return E, Tg, T, np.where(E < 0, -E / par["Lf"], 0.0)
 
@@ -305,3 +310,21 @@ def test_restated_lateral_melt_step_matches_its_closed_form(oracle, coracle):
     got = dict(s, **diag)
     for k, w in want.items():
         assert np.max(np.abs(got[k] / w - 1)) < 1e-12, k
+
+
+def test_restated_classic_ice_with_insolation_follows_the_cellwise_recurrence(oracle, coracle):
+    """The same recurrence with the sun on: albedo by the sign of E, S at this time level in the surface balance and at the
+    next one in the ghost layer (src/classic.jl:47-60), a third of a year from mid-winter."""
+    o = oracle
+    st, par, E0, Tg0 = classic_ice_setup(o)
+    par.update({k: o.default_parameters("Classic")[k] for k in ("S0", "S1", "S2")})
+    n, first = 700, 400
+    idx = (first + np.arange(n)) % st.nt
+    ct = np.array([o.cos2pit(float(t)) for t in st.t])
+    s = dict(E=E0.copy(), Tg=Tg0.copy())
+    out = coracle.classic_run(st.x, par, st.dt, ct[idx], ct[(idx + 1) % st.nt], np.zeros(n), None, s)
+    s.update(out)
+    E, Tg, T, h = classic_ice_recurrence(par, st.dt, E0, Tg0, 0.0, n, st.x, np.roll(st.t, -first))
+    assert ((E0 > 0) & (E < 0)).any() and ((E0 < 0) & (E > 0)).any()
+    for got, want in ((s["E"], E), (s["Tg"], Tg), (s["T"], T), (s["h"], h)):
+        assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 1e-11

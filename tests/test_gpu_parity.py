@@ -1194,3 +1194,24 @@ def test_device_schedule_follows_the_docstring_forcing(pkg):
     record_error("device-side Forcing schedule read back through T0 against the docstring's formula", "f", worst, 1e-11)
     assert worst < 1e-11, worst
     assert abs(pkg.Forcing(0.0, 5.0, -5.0, (10, 10), (0.5, -0.5))(17.57) - 3.785) < 1e-12       # the docstring's own sample
+
+
+def test_classic_ice_with_insolation_follows_the_cellwise_recurrence(pkg, cells):
+    """The classic cell-wise recurrence with the sun on (tests/test_analytic_solutions.py): albedo by the sign of E, S at this
+    time level in the surface balance and at the NEXT one in the ghost layer (src/classic.jl:47-60); 700 steps from
+    mid-winter, cells freezing and melting on the way; run in two calls across the year's wrap of the time table."""
+    from test_analytic_solutions import classic_ice_setup, classic_ice_recurrence
+    st, par, E0, Tg0 = classic_ice_setup(pkg, 200, 2)
+    par.update({k: pkg.default_parameters("Classic")[k] for k in ("S0", "S1", "S2")})
+    n, first = 700, 1600                                             # steps 1600 ... 2299: wraps at 2000
+    with make_engine(pkg, "Classic", st, par, 2) as eng:
+        eng.set_state(dict(E=E0, Tg=Tg0))
+        eng.set_time_table(st.t)
+        eng.run(first, 450, None, False)
+        eng.run(first + 450, n - 450, None, True)
+        got = eng.get_state(("E", "Tg", "T", "h"))
+    E, Tg, T, h = classic_ice_recurrence(par, st.dt, E0, Tg0, 0.0, n, st.x, np.roll(st.t, -first))
+    assert ((E0 > 0) & (E < 0)).any() or ((E0 < 0) & (E > 0)).any()
+    worst = max(float(np.max(np.abs(got[k] - w) / np.maximum(1.0, np.abs(w)))) for k, w in (("E", E), ("Tg", Tg), ("T", T), ("h", h)))
+    record_error("classic ice cell-wise recurrence with insolation, 200 cells, 700 steps", "E, Tg, T, h", worst, 1e-11)
+    assert worst < 1e-11, worst

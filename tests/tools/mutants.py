@@ -54,6 +54,16 @@ MUTANTS = [
     ("annual_mean_divides_by_nt_minus_1", "m.x = s.x / nt;", "m.x = s.x / (nt - 1.0);"),
     ("annual_sum_not_restarted", "z.x = 0.0;", "z.x = s.x;"),
     ("hemispheric_mean_without_the_half", "terms[i] = ieee_div((v[i] + v[i + 1]) * (x[i + 1] - x[i]), 2.0);", "terms[i] = (v[i] + v[i + 1]) * (x[i + 1] - x[i]);"),
+    # fourth batch: code that only the fused-K kernels, savesol!-in-the-step, the extension and the classic solve run
+    # (a seventh mutant of this batch removed the barrier that closed the classic kernel's K-step loop and SURVIVED: the
+    # barrier was redundant — see the comment there — and is gone)
+    ("fused_steps_all_use_the_first_scalars", "const StepSched sc = a.sched[a.slot + step];", "const StepSched sc = a.sched[a.slot];"),
+    ("fused_diagnostics_of_the_first_step", "const bool diag = a.write_diag && step == nloop - 1;", "const bool diag = a.write_diag && step == 0;"),
+    ("running_sum_drops_every_second_cell", "s.y = s.y + x1;", "s.y = s.y + x0;"),
+    ("snapshot_ring_ignores_its_offset", "EBM_STORE2(a.stage + (size_t)v * a.stage_var_stride + a.stage_offset + col_off + kp, d);",
+     "EBM_STORE2(a.stage + (size_t)v * a.stage_var_stride + col_off + kp, d);"),
+    ("extension_lower_diagonal_sign", "ra[i] = -(p.theta_imex * tlo[i]);", "ra[i] = (p.theta_imex * tlo[i]);"),
+    ("classic_ghost_layer_uses_this_steps_sun", "const double S_ip1 = Sb[i] - (p.S1 * ct_next) * xk[i];", "const double S_ip1 = Sb[i] - (p.S1 * ct) * xk[i];"),
     ("classic_surface_temperature_sign", "const double T0 = ieee_div(Cc, p.M - ieee_div(p.kLf, Ek));", "const double T0 = ieee_div(Cc, p.M + ieee_div(p.kLf, Ek));"),
 ]
 

@@ -3,7 +3,7 @@
 # One line per mutant and pass: KILLED by <first failing test> / the anchors that fail, or SURVIVED.
 # Output: gpurun_out/mutants.log
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; : > gpurun_out/mutants.log
-ANCHORS="analytic or closed_form or scalar_recurrence or mode_recurrence or manufactured or step1_closed or melt_through or cellwise_recurrence or couples_ice or lateral_melt or docstring_forcing or integrate_saves_from_registers or hemispheric"
+ANCHORS="analytic or closed_form or scalar_recurrence or mode_recurrence or manufactured or step1_closed or melt_through or cellwise_recurrence or couples_ice or lateral_melt or docstring_forcing or integrate_saves_from_registers or hemispheric or fused_run or with_insolation"
 for lib in build/libebm_mut_*.so; do
   name=$(basename $lib .so); name=${name#libebm_mut_}
   EBM_LIB=$lib timeout -k 10 300 python -m pytest tests -q -m gpu -x -p no:cacheprovider > gpurun_out/mut_$name.txt 2>&1
