@@ -64,6 +64,18 @@ MUTANTS = [
      "EBM_STORE2(a.stage + (size_t)v * a.stage_var_stride + col_off + kp, d);"),
     ("extension_lower_diagonal_sign", "ra[i] = -(p.theta_imex * tlo[i]);", "ra[i] = (p.theta_imex * tlo[i]);"),
     ("classic_ghost_layer_uses_this_steps_sun", "const double S_ip1 = Sb[i] - (p.S1 * ct_next) * xk[i];", "const double S_ip1 = Sb[i] - (p.S1 * ct) * xk[i];"),
+    # fifth batch: the solver's own algebra, the store paths of the two launch geometries, the iteration's control flow
+    ("column_offsets_all_take_the_first", "double f = a.fcol ? ft + a.fcol[col] : ft;", "double f = a.fcol ? ft + a.fcol[0] : ft;"),
+    ("partition_interface_row_sign", "const double RB = __builtin_fma(ce, vn, __builtin_fma(-ae, cp[C - 2], be));", "const double RB = __builtin_fma(ce, vn, __builtin_fma(ae, cp[C - 2], be));"),
+    ("second_level_left_coupling_sign", "lq[i] = -(a2[i] * lq[i - 1]) * w;", "lq[i] = (a2[i] * lq[i - 1]) * w;"),
+    ("cyclic_reduction_lower_sign", "const double nqa = -(qa * am) * r;", "const double nqa = (qa * am) * r;"),
+    ("t0_diagonal_without_olr", "return __builtin_fma(p.k, fast_rcp((hk == 0.0) ? p.hmin : hk), p.B);", "return __builtin_fma(p.k, fast_rcp((hk == 0.0) ? p.hmin : hk), 0.0);"),
+    ("newton_stops_after_one_iteration", "} while (again && it < kMaxNewton);", "} while (false);"),
+    ("warm_start_forgotten", "cmask[tl] = (unsigned short)smask;                // new warm start", "cmask[tl] = (unsigned short)0;                    // new warm start"),
+    ("two_cell_geometry_swaps_h_and_D", "EBM_PUT(S_Ei, Q_Ei) EBM_PUT(S_Ew, Q_Ew) EBM_PUT(S_h, Q_h) EBM_PUT(S_D, Q_D) EBM_PUT(S_phi, Q_phi)",
+     "EBM_PUT(S_Ei, Q_Ei) EBM_PUT(S_Ew, Q_Ew) EBM_PUT(S_h, Q_D) EBM_PUT(S_D, Q_h) EBM_PUT(S_phi, Q_phi)"),
+    ("parked_first_pair_takes_D_for_h", "sEw[0] = v0 ? o[0].q[Q_h] : 0.0;  sEw[T] = v1 ? o[1].q[Q_h] : 0.0;", "sEw[0] = v0 ? o[0].q[Q_D] : 0.0;  sEw[T] = v1 ? o[1].q[Q_h] : 0.0;"),
+    ("classic_ghost_diagonal_ignores_the_melting_mask", "const double q = bool_mul(bool_mul(ieee_div(p.dc, den), T0 < 0.0), Ek < 0.0);", "const double q = bool_mul(ieee_div(p.dc, den), Ek < 0.0);"),
     ("classic_surface_temperature_sign", "const double T0 = ieee_div(Cc, p.M - ieee_div(p.kLf, Ek));", "const double T0 = ieee_div(Cc, p.M + ieee_div(p.kLf, Ek));"),
 ]
 
