@@ -337,3 +337,22 @@ def test_forcing_is_the_references_piecewise_linear_schedule(pkg, oracle, base, 
     assert v == f(T)
     with pytest.raises(ValueError):
         pkg.Forcing(0.0, 1.0, 0.0, (1, 1), (0.3, -1.0))          # warming time 1/0.3 is not an integer
+
+
+def test_default_parameter_values_are_the_published_ones(pkg, oracle):
+    """The default parameter table (src/infrastructure.jl:407-433), value by value, in the host mirror AND in the oracle (two
+    separate transcriptions) against a third statement of them: the first sixteen are Table 1 of Wagner & Eisenman (2015,
+    J. Climate 28, 3998-4014) — D, A, B, cw, S0, S1, S2, a0, a2, ai, Fb, k, Lf, F, cg = 0.01 cw, tau_g — and the MIZ ones are as
+    the reference's comments give them, with the two that it writes as products of a per-second rate and the seconds of a
+    year.  A typo here would change the physics silently: every GPU-vs-oracle test hands the SAME table to both sides."""
+    year = 365 * 24 * 3600
+    want = dict(D=0.6, A=193.0, B=2.1, cw=9.8, S0=420.0, S1=338.0, S2=240.0, a0=0.7, a2=0.1, ai=0.4, Fb=4.0, k=2.0, Lf=9.5, F=0.0,
+                cg=0.01 * 9.8, tau=1e-5, Tm=0.0, m1=1.6e-6 * year, m2=1.36, alpha=0.66, rl=0.5, Dmin=1.0, Dmax=156.0, hmin=0.1,
+                kappa=0.01 * year)
+    assert year == 31536000 and abs(want["m1"] - 50.4576) < 1e-12      # the docstring's printed m1 (src/EnergyBalanceModel.jl:34)
+    for table in (pkg.default_parval, oracle.default_parval):
+        got = dict(table.items()) if hasattr(table, "items") else dict(table)
+        assert set(got) == set(want)
+        for k, v in want.items():
+            assert got[k] == v, (k, got[k], v)
+    assert len(pkg.default_parameters("MIZ")) == 22 and len(pkg.default_parameters("Classic")) == 16
