@@ -356,3 +356,14 @@ def test_default_parameter_values_are_the_published_ones(pkg, oracle):
         for k, v in want.items():
             assert got[k] == v, (k, got[k], v)
     assert len(pkg.default_parameters("MIZ")) == 22 and len(pkg.default_parameters("Classic")) == 16
+
+
+def test_season_indices_round_half_to_even_like_julia(pkg, oracle):
+    """`round(Int, nt*winter)` (src/infrastructure.jl:128-129) rounds to nearest, ties to even — not truncation, not
+    half-up: the docstring's 522 / 1548 at nt = 2000 (522.5 -> 522, 1547.5 -> 1548) and a few made-up seasons."""
+    for kw, nt, want in ((dict(), 2000, (522, 1548)), (dict(winter=0.2661, summer=0.7749), 100, (27, 77)),
+                         (dict(winter=0.265, summer=0.275), 100, (26, 28)), (dict(winter=0.255, summer=0.745), 100, (26, 74))):
+        for mod in (pkg, oracle):
+            st = mod.SpaceTime("identity", 10, nt, 1, **kw)
+            got = (st.winter.inx, st.summer.inx) if mod is pkg else (st.winter_inx, st.summer_inx)
+            assert got == want, (kw, got, want)
