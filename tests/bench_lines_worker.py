@@ -1,0 +1,20 @@
+"""Child of tests/conftest.py (started before the pytest process touches the GPU): runs bench.py a few times with short
+settings, one after the other, and collects the JSON lines for tests/test_gpu_configs.py::test_bench_lines_are_self_consistent.
+This process never initialises the GPU itself; every bench run is its own child."""
+import json, os, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RUNS = [
+    ["--steps", "20", "--repeats", "3", "--spinup", "200", "--preroll", "0.02", "--cpu-budget", "1"],
+    ["--workload", "miz_180x1", "--steps", "64", "--steps-per-launch", "16", "--repeats", "2", "--spinup", "100", "--cpu-budget", "0"],
+    ["--workload", "miz_1024x512x32_integrate", "--steps", "4", "--repeats", "2", "--spinup", "20", "--cpu-budget", "0"],
+    ["--workload", "classic_1024x512", "--steps", "50", "--repeats", "2", "--cpu-budget", "0"],
+]
+out = []
+for args in RUNS:
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, cwd=ROOT)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    out.append({"args": args, "rc": r.returncode, "nlines": len(lines), "line": json.loads(lines[-1]) if lines and r.returncode == 0 else None,
+                "stderr_tail": r.stderr[-600:]})
+with open(sys.argv[1], "w") as fh:
+    json.dump(out, fh)

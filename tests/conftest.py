@@ -22,6 +22,7 @@ def pytest_configure(config):
 # selected and a device is present; tests/test_gpu_configs.py waits for it and checks its output.
 TWO_RANK = {"proc": None, "out": None, "log": None}
 C_EXAMPLE = {"proc": None, "out": None, "err": None}      # examples/c_abi_example.c, same reason
+BENCH_LINES = {"proc": None, "out": None}                 # tests/bench_lines_worker.py, same reason
 
 
 def pytest_sessionstart(session):
@@ -51,6 +52,9 @@ def pytest_sessionstart(session):
     if build.returncode == 0:
         C_EXAMPLE["out"] = os.path.join(tmp, "c_abi_example.out")
         C_EXAMPLE["proc"] = subprocess.Popen([exe], stdout=open(C_EXAMPLE["out"], "w"), stderr=subprocess.STDOUT)
+    BENCH_LINES["out"] = os.path.join(tmp, "bench_lines.json")
+    BENCH_LINES["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_lines_worker.py"), BENCH_LINES["out"]],
+                                           env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     with open(TWO_RANK["log"], "w") as log:
         TWO_RANK["proc"] = subprocess.Popen(
             [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",

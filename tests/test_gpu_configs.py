@@ -332,6 +332,9 @@ def test_no_device_memory_is_left_behind(pkg):
 
     for rep in range(20):
         cycle(rep)
+    for child in (conftest.BENCH_LINES, conftest.TWO_RANK, conftest.C_EXAMPLE):      # they share the device's memory:
+        if child["proc"] is not None:                                                 # let them finish before measuring
+            child["proc"].wait(timeout=900)
     torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info()
     for rep in range(20):
@@ -339,3 +342,47 @@ def test_no_device_memory_is_left_behind(pkg):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert abs(free0 - free1) <= 8 * 2**20, (free0, free1)
+
+
+def test_bench_lines_are_self_consistent(pkg):
+    """bench.py itself, run four ways with short settings by a child that conftest started before this process touched the
+    GPU (headline + CPU baseline, fused-K, integrate, classic): exactly one JSON line each, the contract's keys, and the
+    numbers consistent with each other — value = cells x steps / time, the median block, roofline.achieved = algorithmic
+    bytes / HIP-event launch time, frac = achieved / 8 TB/s, the metric string of BASELINE.json on the headline only."""
+    import json
+    proc = conftest.BENCH_LINES["proc"]
+    if proc is None:
+        pytest.skip("bench child not started (no -m gpu session start)")
+    assert proc.wait(timeout=900) == 0
+    runs = json.load(open(conftest.BENCH_LINES["out"]))
+    assert len(runs) == 4
+    cells = {0: 4096 * 2048, 1: 180, 2: 1024 * 16384, 3: 1024 * 512}
+    for i, r in enumerate(runs):
+        assert r["rc"] == 0 and r["nlines"] == 1, (i, r["stderr_tail"])
+        d = r["line"]
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in d, (i, k)
+        assert d["unit"] == "grid-cell-steps/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+        assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
+        assert d["steps"] == int(r["args"][r["args"].index("--steps") + 1])
+        assert abs(d["value"] * d["ms_per_step"] * 1e-3 / cells[i] - 1.0) < 1e-9                  # value = cells x steps / time
+        blocks = sorted(d["blocks_ms_per_step"])
+        assert len(blocks) == d["repeats"] and blocks[0] <= d["ms_per_step"] <= blocks[-1]
+        ro = d["roofline"]
+        assert ro["bound"] == "hbm" and ro["peak"] == 8000.0 and ro["unit"] == "GB/s"
+        assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
+        spl = d["config"]["steps_per_launch"]
+        assert abs(ro["algorithmic_bytes_per_launch"] - ro["algorithmic_bytes_per_cell_step"] * cells[i] * spl) < 1e-3
+        assert abs(ro["achieved"] - ro["algorithmic_bytes_per_launch"] / (ro["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * ro["achieved"]
+        assert ro["avg_launch_ms"] <= 1.05 * (d.get("ms_per_step_excluding_year_end") or d["ms_per_step"]) * spl
+    head, fused, integ, classic = (r["line"] for r in runs)
+    assert head["metric"] == "grid-cell-steps/sec (2D 4096x2048 MIZ model)" and "4096 lat x 2048 meridians" in head["config"]["workload"]
+    assert head["roofline"]["algorithmic_bytes_per_cell_step"] == 96.0 and head["config"]["steps_per_launch"] == 1.0
+    assert head["roofline"]["traffic"] and "NOT measured in this run" in head["roofline"]["traffic_source"]
+    cb = head["cpu_baseline"]
+    assert cb and cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "grid-cell-steps/s" and cb["sample"]
+    assert all(r["line"]["cpu_baseline"] is None for r in runs[1:])
+    assert "fused" in fused["metric"] and fused["config"]["steps_per_launch"] == 16.0 and fused["roofline"]["kernel"] == "miz_fused_kernel"
+    assert integ["roofline"]["algorithmic_bytes_per_cell_step"] == 256.0 and integ["year_end_ms"] >= 0.0
+    assert classic["roofline"]["algorithmic_bytes_per_cell_step"] == 32.0 and classic["roofline"]["kernel"] == "classic_step_kernel"
