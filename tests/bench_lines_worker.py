@@ -1,5 +1,6 @@
 """Child of tests/conftest.py (started before the pytest process touches the GPU): runs bench.py a few times with short
-settings, one after the other, and collects the JSON lines for tests/test_gpu_configs.py::test_bench_lines_are_self_consistent.
+settings, one after the other, and collects the JSON lines for tests/test_gpu_configs.py::test_bench_lines_are_self_consistent;
+then examples/hysteresis_ensemble.py, small, for test_hysteresis_example_runs.
 This process never initialises the GPU itself; every bench run is its own child."""
 import json, os, subprocess, sys
 
@@ -16,5 +17,9 @@ for args in RUNS:
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     out.append({"args": args, "rc": r.returncode, "nlines": len(lines), "line": json.loads(lines[-1]) if lines and r.returncode == 0 else None,
                 "stderr_tail": r.stderr[-600:]})
+# and the hysteresis example end to end, small
+r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "hysteresis_ensemble.py"), "--members", "8", "--nlat", "90", "--nt", "500"],
+                   capture_output=True, text=True, cwd=ROOT)
+out.append({"args": ["hysteresis_ensemble.py"], "rc": r.returncode, "stdout": r.stdout, "stderr_tail": r.stderr[-600:]})
 with open(sys.argv[1], "w") as fh:
     json.dump(out, fh)

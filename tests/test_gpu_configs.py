@@ -354,7 +354,7 @@ def test_bench_lines_are_self_consistent(pkg):
     if proc is None:
         pytest.skip("bench child not started (no -m gpu session start)")
     assert proc.wait(timeout=900) == 0
-    runs = json.load(open(conftest.BENCH_LINES["out"]))
+    runs = json.load(open(conftest.BENCH_LINES["out"]))[:4]
     assert len(runs) == 4
     cells = {0: 4096 * 2048, 1: 180, 2: 1024 * 16384, 3: 1024 * 512}
     for i, r in enumerate(runs):
@@ -386,3 +386,31 @@ def test_bench_lines_are_self_consistent(pkg):
     assert "fused" in fused["metric"] and fused["config"]["steps_per_launch"] == 16.0 and fused["roofline"]["kernel"] == "miz_fused_kernel"
     assert integ["roofline"]["algorithmic_bytes_per_cell_step"] == 256.0 and integ["year_end_ms"] >= 0.0
     assert classic["roofline"]["algorithmic_bytes_per_cell_step"] == 32.0 and classic["roofline"]["kernel"] == "classic_step_kernel"
+
+
+def test_hysteresis_example_runs(pkg):
+    """examples/hysteresis_ensemble.py end to end (8 members, 90 latitudes, 500 steps per year, 38 years; started by
+    conftest's child): per-member `Forcing{false}` schedules on the device, `savesol!` in the step, the seasonal outputs
+    reduced to per-member hemispheric means on the device.  The printed table is parsed: the forcing schedules, the
+    ordering winter >= annual >= summer ice area, warming under the ramp, identical members before the ramps begin."""
+    import json
+    import re
+    proc = conftest.BENCH_LINES["proc"]
+    if proc is None:
+        pytest.skip("example child not started (no -m gpu session start)")
+    assert proc.wait(timeout=900) == 0
+    r = json.load(open(conftest.BENCH_LINES["out"]))[4]
+    assert r["rc"] == 0, r["stderr_tail"]
+    lines = r["stdout"].splitlines()
+    assert lines[0].startswith("8 members x 90 latitudes, 38 years of 500 steps on 1 GPU(s)")
+    rows = [l for l in lines if l.startswith("year")]
+    assert len(rows) == 38
+    table = np.array([[float(v) for v in re.findall(r"-?\d+\.\d+", l.split("f =")[1])] for l in rows])
+    assert table.shape == (38, 20) and np.isfinite(table).all()
+    f, T, area = table[:, :4], table[:, 4:8], table[:, 8:].reshape(38, 4, 3)          # area: annual mean / winter / summer
+    assert f.max() == 8.0 and not f[-1].any() and not f[:2].any()                   # 2 years of hold, up to 8 W/m2, back to 0
+    assert f[3, 0] == 6.0 and f[6, 0] == 6.0 and f[4, 0] == 8.0                     # member 0 ramps at 4 W/m2 per year
+    assert (np.diff(f[2:11, 2]) > 0).all()                                          # member 2 at 1 W/m2 per year
+    assert (area[:, :, 1] >= area[:, :, 0]).all() and (area[:, :, 0] >= area[:, :, 2]).all()      # winter >= annual >= summer ice
+    assert T[7, 0] > T[0, 0] + 10.0 and (area[7, :, 0] < area[0, :, 0]).all()      # warming melts ice
+    assert (T[:2] == T[:2, :1]).all()                                               # identical members until the ramps begin
