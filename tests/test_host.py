@@ -367,3 +367,15 @@ def test_season_indices_round_half_to_even_like_julia(pkg, oracle):
             st = mod.SpaceTime("identity", 10, nt, 1, **kw)
             got = (st.winter.inx, st.summer.inx) if mod is pkg else (st.winter_inx, st.summer_inx)
             assert got == want, (kw, got, want)
+
+
+def test_integration_doc_lists_every_exported_symbol():
+    """INTEGRATION.md is the page a maintainer of the reference binds from: every entry point that include/ebm_hip.h
+    declares appears in it (`ebm_timer_*`-style wildcards do not count)."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "ebm_hip.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    syms = sorted(set(re.findall(r"\b(ebm_[a-z_]+)\s*\(", hdr)))
+    assert len(syms) >= 27
+    missing = [s for s in syms if not re.search(r"\b" + s + r"\b", doc)]
+    assert not missing, missing
