@@ -19,6 +19,9 @@ thread_local std::string g_err;
 
 int fail(int code, const std::string &msg) {
     g_err = msg;
+    // a failed runtime call leaves its code as the thread's "last error", which the next kernel launch's
+    // hipGetLastError() check would report as its own: the failure has been reported here, so clear it
+    if (code == EBM_ERR_HIP) (void)hipGetLastError();
     return code;
 }
 #define HIPCHK(expr)                                                                       \

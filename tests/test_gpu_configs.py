@@ -414,3 +414,30 @@ def test_hysteresis_example_runs(pkg):
     assert (area[:, :, 1] >= area[:, :, 0]).all() and (area[:, :, 0] >= area[:, :, 2]).all()      # winter >= annual >= summer ice
     assert T[7, 0] > T[0, 0] + 10.0 and (area[7, :, 0] < area[0, :, 0]).all()      # warming melts ice
     assert (T[:2] == T[:2, :1]).all()                                               # identical members until the ramps begin
+
+
+def test_out_of_memory_is_an_error_not_a_crash(pkg):
+    """A handle that cannot fit — 4096 x 2,000,000 meridians, 720 GB of state on a 288 GB card — is refused with the
+    runtime's message, leaves nothing behind, and does not poison what comes after it in the same thread (a failed HIP call
+    stays the thread's "last error" until cleared: the next launch's own check must not report it)."""
+    import torch
+    st = pkg.SpaceTime("sin", 4096, 1048576, 1)
+    par = pkg.default_parameters("MIZ")
+    pv = pkg.engine.param_vector(par, pkg.default_parval)
+    with pkg.Engine("MIZ", st.grid_kind, st.x, pv, st.dt, 4, device=0) as eng:      # warm: kernels loaded
+        eng.set_time_table(st.t)
+        eng.run(0, 2)
+    for child in (conftest.BENCH_LINES, conftest.TWO_RANK, conftest.C_EXAMPLE):
+        if child["proc"] is not None:
+            child["proc"].wait(timeout=900)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    with pytest.raises(pkg.EBMError, match="(?i)memory|alloc"):
+        pkg.Engine("MIZ", st.grid_kind, st.x, pv, st.dt, 2_000_000, device=0)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free0 - free1) <= 8 * 2**20, (free0, free1)
+    with pkg.Engine("MIZ", st.grid_kind, st.x, pv, st.dt, 4, device=0) as eng:
+        eng.set_time_table(st.t)
+        eng.run(0, 3, None, True)
+        assert np.isfinite(eng.get_field("Ew")).all() and eng.counters()["steps"] == 3
