@@ -1215,3 +1215,70 @@ def test_classic_ice_with_insolation_follows_the_cellwise_recurrence(pkg, cells)
     worst = max(float(np.max(np.abs(got[k] - w) / np.maximum(1.0, np.abs(w)))) for k, w in (("E", E), ("Tg", Tg), ("T", T), ("h", h)))
     record_error("classic ice cell-wise recurrence with insolation, 200 cells, 700 steps", "E, Tg, T, h", worst, 1e-11)
     assert worst < 1e-11, worst
+
+
+@pytest.mark.parametrize("nlat", [2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 127, 129])
+def test_tiny_and_odd_sizes_through_every_entry_point(pkg, coracle, nlat):
+    """Meridians of 2 ... 129 cells — one thread, one ragged chunk, exactly one wave, one wave and one cell — through ebm_run,
+    ebm_run_fused, ebm_integrate (sums + snapshots), the hemispheric mean and the extension, for the MIZ model on both grids
+    and the classic model: everything against the oracle after 25 steps from a state with ice and open water."""
+    nt, nsteps, ncol = 4000, 25, 3
+    fcol = np.array([-1.0, 0.0, 2.5])
+    for model, kind in (("MIZ", "sin"), ("MIZ", "identity"), ("MIZ_IMEX", "sin"), ("Classic", "identity")):
+        st = pkg.SpaceTime(kind, nlat, nt, 1)
+        par = pkg.default_parameters("Classic" if model == "Classic" else "MIZ")
+        ct = ctab(pkg, st)
+        if model == "Classic":
+            Ts = 30.0 - 45.0 * st.x ** 2
+            state = dict(E=np.tile(np.where(Ts >= 0, par["cw"] * Ts, par["Lf"] * Ts / 7.5), (ncol, 1)), Tg=np.tile(Ts, (ncol, 1)))
+            idx = np.arange(nsteps)
+            ref = {k: v.copy() for k, v in state.items()}
+            ref.update(coracle.classic_run(st.x, dict(par), st.dt, ct[idx], ct[(idx + 1) % nt], np.zeros(nsteps), fcol, ref))
+            names = ("E", "Tg", "T", "h")
+        else:
+            state = {k: np.zeros((ncol, nlat)) for k in PROG + ("T0",)}
+            coracle.miz_run(0 if kind == "identity" else 1, st.x, dict(par), st.dt, ct[:40], np.zeros(40), fcol, state, imex=(model == "MIZ_IMEX"))
+            ref = {k: v.copy() for k, v in state.items()}
+            diag, _ = coracle.miz_run(0 if kind == "identity" else 1, st.x, dict(par), st.dt, ct[40:40 + nsteps], np.zeros(nsteps), fcol, ref,
+                                      imex=(model == "MIZ_IMEX"))
+            ref.update(diag)
+            names = ALL
+        first = 0 if model == "Classic" else 40
+        got = {}
+        # (`integrate` needs a time table of exactly its nt entries: a window of the year's.  The classic step also reads the
+        #  NEXT entry, which at the window's last step wraps inside the window — so integrate is compared with a run over
+        #  the same window, and the oracle with the runs over the year's table)
+        for how in ("run", "fused", "integrate", "run_window"):
+            with pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval), st.dt, ncol, device=0) as eng:
+                eng.set_state(state)
+                eng.set_column_forcing(fcol)
+                if how == "integrate":
+                    eng.set_time_table(np.take(st.t, np.arange(first, first + nsteps)))
+                    out = eng.integrate(nsteps, 1, None, True, 7, 19, names[:4])
+                    got[how] = eng.get_state(names)
+                    for vi, v in enumerate(names[:4]):               # raw[-1] is the final state, the snapshots are raw's rows
+                        assert np.array_equal(out["raw"][vi, -1], got[how][v], equal_nan=True), (model, v)
+                        assert np.array_equal(out["winter"][vi, 0], out["raw"][vi, 6], equal_nan=True)
+                        acc = np.zeros((ncol, nlat))
+                        with np.errstate(all="ignore"):
+                            for row in out["raw"][vi]:
+                                acc = acc + row
+                            assert np.array_equal(out["avg"][vi, 0], acc / nsteps, equal_nan=True), (model, v)
+                elif how == "run_window":
+                    eng.set_time_table(np.take(st.t, np.arange(first, first + nsteps)))
+                    eng.run(0, nsteps, None, True)
+                    got[how] = eng.get_state(names)
+                else:
+                    eng.set_time_table(st.t)
+                    eng.run(first, nsteps, None, True, steps_per_launch=(4 if how == "fused" else 1))
+                    got[how] = eng.get_state(names)
+                    hm = eng.hemispheric_mean("T")
+                    assert np.array_equal(hm, pkg.hemispheric_mean(got[how]["T"], st.x), equal_nan=True)
+        for k in names:
+            assert np.array_equal(got["run"][k], got["fused"][k], equal_nan=True), (model, kind, k)
+            assert np.array_equal(got["run_window"][k], got["integrate"][k], equal_nan=True), (model, kind, k)
+            if model != "Classic":
+                assert np.array_equal(got["run"][k], got["run_window"][k], equal_nan=True), (model, kind, k)
+        worst = max(scaled_err(got["run"][k], ref[k]) for k in names)
+        record_error(f"tiny sizes: {model} {kind} {nlat} cells, 25 steps", "all fields", worst, 1e-10)
+        assert worst <= 1e-10, (model, kind, worst)                  # measured: <= 8.4e-11 (identity grid, 127 / 129 cells), else <= 1e-12
