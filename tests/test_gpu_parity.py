@@ -1282,3 +1282,90 @@ def test_tiny_and_odd_sizes_through_every_entry_point(pkg, coracle, nlat):
         worst = max(scaled_err(got["run"][k], ref[k]) for k in names)
         record_error(f"tiny sizes: {model} {kind} {nlat} cells, 25 steps", "all fields", worst, 1e-10)
         assert worst <= 1e-10, (model, kind, worst)                  # measured: <= 8.4e-11 (identity grid, 127 / 129 cells), else <= 1e-12
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_call_sequences_track_the_oracle(pkg, coracle, seed):
+    """Stateful fuzz of the handle: random sequences of the calls a driver makes — runs of 1 ... 200 steps with one launch
+    per step (long ones replay the captured graph), fused runs, per-step forcing series, new column offsets in between
+    (the graph must be rebuilt), per-column schedules switched on and off, prognostic fields overwritten from the host, the
+    T0 warm start overwritten with garbage (the solution must not care), single `ebm_step` calls, the step clock moved —
+    mirrored on the oracle operation by operation, 600 steps in all, every field compared after every run.  What is fuzzed
+    is the handle's bookkeeping (clock, time-table wrap, tables behind a captured graph, forcing plumbing), so the model runs
+    in a benign regime — open water without insolation, where it is linear (tests/test_analytic_solutions.py) — and the bar
+    can stay at 1e-10 (measured: <= 1.7e-11, mostly T0 of the decoupled open-water rows): from the zero state the same sequences make the MODEL amplify rounding until the fp64 oracle is 1e-5
+    from its own 80-bit build, and no bar means anything."""
+    rng = np.random.default_rng(900 + seed)
+    kind = "identity" if seed % 2 else "sin"
+    nlat, ncol, nt = int(rng.choice([64, 180, 333])), 3, 16000
+    st = pkg.SpaceTime(kind, nlat, nt, 3)
+    par = dict(pkg.default_parameters("MIZ"))
+    par.update(S0=0.0, S1=0.0, S2=0.0, A=0.0, Fb=0.0)
+    kid = 0 if kind == "identity" else 1
+    ct = ctab(pkg, st)
+    x = st.x
+    state = {k: np.zeros((ncol, nlat)) for k in PROG + ("T0",)}
+    state["Ew"] = par["cw"] * np.outer(1.0 + 0.1 * np.arange(ncol), 10.0 + (3 * x**2 - 1) / 2 + 0.5 * (35 * x**4 - 30 * x**2 + 3) / 8)
+    fcol = np.zeros(ncol)
+    scheds = None
+    clock, total, worst, compared = int(rng.integers(0, 2 * nt)), 0, 0.0, 0
+
+    def oracle_advance(first, n, f_steps):
+        idx = (first + np.arange(n)) % nt
+        base = np.zeros(n) if f_steps is None else f_steps
+        if scheds is None:
+            return coracle.miz_run(kid, st.x, dict(par), st.dt, ct[idx], base, fcol, state)[0]
+        diag = {}
+        for c in range(ncol):
+            extra = np.array([scheds[c](float(st.T[(first + i) % len(st.T)])) for i in range(n)])
+            sub = {k: v[c:c + 1].copy() for k, v in state.items()}
+            d, _ = coracle.miz_run(kid, st.x, dict(par), st.dt, ct[idx], base + extra, fcol[c:c + 1], sub)
+            for k, v in sub.items():
+                state[k][c] = v[0]
+            for k, v in d.items():
+                diag.setdefault(k, np.zeros((ncol, nlat)))[c] = v[0]
+        return diag
+
+    with make_engine(pkg, "MIZ", st, par, ncol) as eng:
+        eng.set_state(state)
+        eng.set_time_table(st.t)
+        eng.set_step_clock(clock)
+        while total < 600:
+            op = rng.choice(["run", "run", "long_run", "fused", "fcol", "sched", "poke", "t0", "step", "jump"])
+            if op in ("run", "long_run", "fused"):
+                n = int(rng.integers(130, 200)) if op == "long_run" else int(rng.integers(1, 40))
+                n = min(n, 600 - total)
+                f_steps = None if rng.random() < 0.5 else rng.normal(0.0, 1.0, n)
+                eng.run(clock, n, f_steps, True, steps_per_launch=(int(rng.integers(2, 9)) if op == "fused" else 1))
+                diag = oracle_advance(clock, n, f_steps)
+                clock, total = clock + n, total + n
+                got = eng.get_state(ALL)
+                e = max(scaled_err(got[k], dict(state, **diag)[k]) for k in ALL)
+                worst, compared = max(worst, e), compared + 1
+                assert e <= 1e-10, (op, n, total, e)
+            elif op == "fcol":
+                fcol = rng.uniform(-3.0, 3.0, ncol)
+                eng.set_column_forcing(fcol)
+            elif op == "sched":
+                if (st.T[-1] - clock / nt) < 1.5:                    # schedules are defined over the run's duration
+                    continue
+                scheds = None if scheds is not None else [pkg.Forcing(0.0, 2.0 * (c + 1), -1.0, (0, 1), (2.0 * (c + 1), -1.0 - 2.0 * (c + 1)))
+                                                         for c in range(ncol)]
+                eng.set_column_schedules(scheds)
+            elif op == "poke":
+                state["Ew"] = state["Ew"] * float(rng.uniform(0.9, 1.1))
+                eng.set_field("Ew", state["Ew"])
+            elif op == "t0":
+                eng.set_field("T0", rng.normal(0.0, 5.0, (ncol, nlat)))        # garbage warm start: only its signs are used
+            elif op == "jump":
+                clock = int(rng.integers(0, 2 * nt))                 # a driver restarting elsewhere in the schedule
+                eng.set_step_clock(clock)
+            else:
+                f = float(rng.normal())
+                eng.step(ct[clock % nt], ct[(clock + 1) % nt], f, True)
+                oracle_advance(clock, 1, np.array([f]))
+                clock, total = clock + 1, total + 1
+                eng.set_step_clock(clock)
+        cnt = eng.counters()
+    record_error(f"random call sequence, seed {seed}: {kind} {nlat}, 600 steps, {compared} comparisons", "all fields", worst, 1e-10)
+    assert compared >= 5 and cnt["cap_hits"] == 0, compared
