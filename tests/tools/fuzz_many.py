@@ -1,5 +1,5 @@
 """The one-step state fuzz of tests/test_gpu_parity.py::test_randomized_states_one_step over many more seeds than the suite
-runs (GPU box): python tests/tools/fuzz_many.py [first] [count] — prints the seeds that fail and the worst error seen."""
+runs (GPU box): python tests/tools/fuzz_many.py [first] [count] [miz|classic] — prints the seeds that fail and the worst error seen."""
 import os, sys
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -20,12 +20,16 @@ class Env:                                                            # the one 
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+which = sys.argv[3] if len(sys.argv) > 3 else "miz"                    # "miz" or "classic"
 conftest.record_error = lambda *a, **k: None
 T.record_error = lambda *a, **k: None
 bad = []
 for seed in range(first, first + count):
     try:
-        T.test_randomized_states_one_step(pkg, coracle, seed, Env())
+        if which == "classic":
+            T.test_classic_randomized_states_one_step(pkg, coracle, seed, Env())
+        else:
+            T.test_randomized_states_one_step(pkg, coracle, seed, Env())
     except AssertionError as e:
         bad.append(seed)
         print("seed", seed, "FAILED:", str(e).splitlines()[0][:200], flush=True)
