@@ -242,16 +242,23 @@ __device__ __forceinline__ void halo_exchange(double *E0, double *E1, int t, int
 //  4. Back-substitute inside the chunk.
 // P0/P1: 3T doubles each.  On entry P1 must be free and P0 free after the first barrier inside;
 // on exit other threads may still be reading P0/P1 (callers put a barrier before reuse).
-#ifndef EBM_SECOND_LEVEL_ROWS
-#define EBM_SECOND_LEVEL_ROWS 4
+// Rows per thread of the second level: 4 — except for the shortest workgroups (T <= 128: one or two waves, the
+// 180-band shapes), where 2 rows per thread, i.e. one more reduction level on a shorter serial chain, is 1-2 % faster
+// (180 x 1: 5.63 -> 5.58 us per step, fused 3.54 -> 3.50; 180 x 8192: 42.9 -> 42.1) while it costs 2-3 % on the
+// 4096-cell shape (0.1688 vs 0.1644 ms; 8 rows: 0.1681).  -DEBM_SECOND_LEVEL_ROWS=n fixes it for A/B builds.
+constexpr int second_level_rows(int T) {
+#ifdef EBM_SECOND_LEVEL_ROWS
+    return EBM_SECOND_LEVEL_ROWS;
+#else
+    return T <= 128 ? 2 : 4;
 #endif
-constexpr int kSecondLevelRows = EBM_SECOND_LEVEL_ROWS;
+}
 
-template <int C>
-__device__ __forceinline__ void partition_solve(const double (&a)[C], const double (&b)[C],
-                                                const double (&c)[C], const double (&d)[C],
-                                                double (&x)[C], int t, int T, double *P0,
-                                                double *P1) {
+template <int C, int R>
+__device__ __forceinline__ void partition_solve_r(const double (&a)[C], const double (&b)[C],
+                                                  const double (&c)[C], const double (&d)[C],
+                                                  double (&x)[C], int t, int T, double *P0,
+                                                  double *P1) {
     double cp[C - 1], dp[C - 1], lp[C - 1];
     {
         const double w = fast_rcp(b[0]);
@@ -300,7 +307,6 @@ __device__ __forceinline__ void partition_solve(const double (&a)[C], const doub
     // G second-level interface rows go through parallel cyclic reduction.  Waves beyond the first
     // G threads only take part in the barriers.  Rows are exchanged through LDS transposed
     // (row q of group g at [q*G + g]) so that both sides access consecutive words.
-    constexpr int R = kSecondLevelRows;
     const int G = T / R;
     const bool lvl2 = t < G;
     {
@@ -311,7 +317,10 @@ __device__ __forceinline__ void partition_solve(const double (&a)[C], const doub
     }
     __syncthreads();
     double a2[R], c2[R], d2[R], cq[R - 1], dq[R - 1], lq[R - 1];
-    double *U = P1, *S0 = P1 + 3 * G, *S1 = P1 + 6 * G;
+    // U is dead once every second-level thread has read its neighbour's entry, i.e. after the barrier that follows the
+    // S0 writes: the reduction's second buffer reuses it, and P1's 3T doubles suffice for R = 2 as well (6G = 3T)
+    double *U = P1, *S0 = P1 + 3 * G, *S1 = P1;
+    static_assert(R == 2 || R == 4 || R == 8, "second-level rows: P1 holds 6 T / R doubles");
     if (lvl2) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -407,6 +416,14 @@ __device__ __forceinline__ void partition_solve(const double (&a)[C], const doub
     x[C - 1] = pd;
 #pragma unroll
     for (int i = C - 2; i >= 0; --i) x[i] = __builtin_fma(-cp[i], x[i + 1], __builtin_fma(lp[i], L, dp[i]));
+}
+// TT: the workgroup size if it is a compile-time constant (the MIZ kernels), 0 if only known at run time (classic)
+template <int C, int TT = 0>
+__device__ __forceinline__ void partition_solve(const double (&a)[C], const double (&b)[C],
+                                                const double (&c)[C], const double (&d)[C],
+                                                double (&x)[C], int t, int T, double *P0, double *P1) {
+    // (run-time T: one copy of the solve only — two would take the classic K-step kernel past its 128 VGPRs)
+    partition_solve_r<C, second_level_rows(TT != 0 ? TT : 1024)>(a, b, c, d, x, t, T, P0, P1);
 }
 
 // ---- MIZ pointwise physics (one cell), bit-exact restatement of src/miz.jl:160-194 ----------
@@ -548,7 +565,7 @@ __device__ __forceinline__ double insolation(ConstParams &p, double xk, double c
 // T0 < Tm in cell i of this thread), tridiagonal solve, new active set; returns whether any thread's
 // set changed.  P0/P1 must be free on entry; on exit every thread has passed a barrier after its last
 // LDS access.
-template <int C>
+template <int C, int TT>
 __device__ __forceinline__ bool newton_iteration(const double (&lo)[C], const double (&up)[C],
                                                  const double (&dd)[C], const double (&ph)[C],
                                                  const double (&rd)[C], double (&xs)[C], unsigned &smask,
@@ -565,7 +582,7 @@ __device__ __forceinline__ bool newton_iteration(const double (&lo)[C], const do
         rc[i] = up[i] * (i < C - 1 ? g[i < C - 1 ? i + 1 : i] : gr);
         rb[i] = -__builtin_fma(lo[i] + up[i], g[i], dd[i]);
     }
-    partition_solve<C>(ra, rb, rc, rd, xs, t, T, P0, P1);
+    partition_solve<C, TT>(ra, rb, rc, rd, xs, t, T, P0, P1);
     unsigned snew = 0;
 #pragma unroll
     for (int i = 0; i < C; ++i) snew |= (xs[i] < 0.0) ? (1u << i) : 0u;
@@ -702,7 +719,7 @@ __global__ void __launch_bounds__(1024) miz_step_kernel(const StepArgs a) {
         EBM_STAMP(3);
         // ---------------- phase B: active-set Newton, src/miz.jl:33-68 --------------------
         ++it;
-        again = newton_iteration<C>(tlo, tup, dd, ph, rd, xs, smask, t, T, k0, nlat, P0, P1);
+        again = newton_iteration<C, TT>(tlo, tup, dd, ph, rd, xs, smask, t, T, k0, nlat, P0, P1);
     } while (again && it < kMaxNewton);
     if (t == 0 && a.counters) {
         unsigned long long *cnt = a.counters + 2 * (col % kCounterShards);
@@ -808,7 +825,7 @@ __global__ void __launch_bounds__(1024) miz_step_kernel(const StepArgs a) {
                 rc[i] = -(p.theta_imex * tup[i]);
                 rb[i] = 1.0 + p.theta_imex * (tlo[i] + tup[i]);
             }
-            partition_solve<C>(ra, rb, rc, dE, sol, t, T, P0, P1);
+            partition_solve<C, TT>(ra, rb, rc, dE, sol, t, T, P0, P1);
         }
         __syncthreads();                                  // the solve's LDS reads are done before P0 is reused
         {
@@ -1020,7 +1037,7 @@ __global__ void __launch_bounds__(TT) miz_fused_kernel(const StepArgs a) {
         bool again = true;
         while (again && it < kMaxNewton) {
             ++it;
-            again = newton_iteration<C>(tlo, tup, dd, ph, rd, xs, smask, t, T, k0, nlat, P0, P1);
+            again = newton_iteration<C, TT>(tlo, tup, dd, ph, rd, xs, smask, t, T, k0, nlat, P0, P1);
         }
         nit += it;
         nfail += again ? 1 : 0;
