@@ -200,6 +200,10 @@ def main():
     eng.sync()
     per_step = (time.perf_counter() - t0) / probe
     preroll = 0 if integrate else int(min(200000, max(0, args.preroll / max(per_step, 1e-7))))
+    if preroll > nt:
+        # short years (the 180-band workloads: 2000 steps): whole years only, so that every run is timed at the same point of
+        # the seasonal cycle — the T0 iteration count, hence the time per step, depends on it (+-3 % otherwise)
+        preroll = (preroll // nt) * nt
     if preroll:
         advance(preroll)
     advance(args.warmup) if args.warmup else None

@@ -242,15 +242,15 @@ __device__ __forceinline__ void halo_exchange(double *E0, double *E1, int t, int
 //  4. Back-substitute inside the chunk.
 // P0/P1: 3T doubles each.  On entry P1 must be free and P0 free after the first barrier inside;
 // on exit other threads may still be reading P0/P1 (callers put a barrier before reuse).
-// Rows per thread of the second level: 4 — except for the shortest workgroups (T <= 128: one or two waves, the
-// 180-band shapes), where 2 rows per thread, i.e. one more reduction level on a shorter serial chain, is 1-2 % faster
-// (180 x 1: 5.63 -> 5.58 us per step, fused 3.54 -> 3.50; 180 x 8192: 42.9 -> 42.1) while it costs 2-3 % on the
-// 4096-cell shape (0.1688 vs 0.1644 ms; 8 rows: 0.1681).  -DEBM_SECOND_LEVEL_ROWS=n fixes it for A/B builds.
-constexpr int second_level_rows(int T) {
+// Rows per thread of the second level: 4 at every workgroup size.  Measured with each variant passing
+// test_every_workgroup_size (tests/tools/ab_variants.sh): 2 rows 0.1688, 8 rows 0.1681 against 0.1644 ms on the
+// 4096 x 2048 shape; 2 rows for T <= 128 only (the 180-band shapes): within 0.3 % of 4 rows once the benchmark's state
+// is pinned (--preroll 0).  -DEBM_SECOND_LEVEL_ROWS=n (2, 4 or 8) for A/B builds.
+constexpr int second_level_rows(int /*T*/) {
 #ifdef EBM_SECOND_LEVEL_ROWS
     return EBM_SECOND_LEVEL_ROWS;
 #else
-    return T <= 128 ? 2 : 4;
+    return 4;
 #endif
 }
 
