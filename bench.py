@@ -12,6 +12,15 @@ scaling, no collective in the time loop).
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process — before it has made any GPU call —
+starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...  bench.py
+<same arguments>` as a CHILD, relays rank 0's JSON line and exits with the child's return code.  With fewer
+than N devices visible it exits non-zero and says so: an N-GPU number is never reported from fewer GPUs
+(EBM_BENCH_BACKEND=gloo lets ranks share a device to REHEARSE the N > 1 path on a one-GPU box; the line then
+carries `"backend": "gloo"` and `devices_used` < n_gpus).  Started by a launcher (WORLD_SIZE set), `--gpus` must
+equal the world size.  The line reports `n_gpus`, the backend, the world size the process group saw and every
+rank's own block timings (`ranks`).
+
 Order of events: spin-up -> pre-roll (>= 0.25 s of untimed steps, so that the GPU is at its working
 clocks whatever `--warmup` says) -> W warm-up steps -> `--repeats` blocks of EXACTLY K steps, each
 bracketed by barrier + synchronize on both sides and timed with the host clock (max over ranks) and
@@ -23,6 +32,11 @@ Other workloads (never the headline; `metric` names them):
         the fused-K path (ebm_run_fused: K steps per launch, state in registers), reported separately
   --workload miz_1024x512x32_integrate   ebm_integrate with the annual-mean sums of all 10 solution
         variables taken from the step kernel's registers (savesol! fused; avg on, raw off)
+  --workload miz_1024x512x32   the per-GPU share of BASELINE configs[4] (256 members of 1024 x 512 over 8 GPUs:
+        32 members per GPU, member forcing by global member index): the ensemble weak-scaling leg
+  --workload miz_4096x2048_step   the headline grid with step! semantics: EVERY step writes T0 and the five
+        diagnostic fields as well (ebm_step(write_diag = 1), src/miz.jl:150-196 returns all ten variables
+        every call): 144 B per cell-step
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per cell-step (MIZ: 96 B =
 read + write of Ei, Ew, h, D, phi and the T0 warm start; integrate: + 16 B per saved
@@ -60,6 +74,8 @@ WORKLOADS = {
     # the implicit-diffusion EXTENSION (not in the reference): the headline grid at the reference test's 2000
     # steps per year, 520x beyond the explicit limit of the reference's own step
     "miz_imex_4096x2048": ("MIZ_IMEX", "sin", 4096, 2048, 2000),
+    # step! semantics on the headline grid: every step also writes T0 and the five diagnostic fields
+    "miz_4096x2048_step": ("MIZ", "sin", 4096, 2048, 1048576),
 }
 MIZ_VARS = ("E", "T", "h", "Ei", "Ew", "Ti", "Tw", "D", "phi", "n")
 
@@ -111,9 +127,58 @@ def cells_bytes(nlat, ncol):
     return 8.0 * nlat * ncol
 
 
+def spawn_ranks(ngpus: int, argv: list) -> int:
+    """`python bench.py --gpus N` (N > 1, no launcher): start N ranks as a CHILD process group and relay
+    rank 0's line.  This process must not have touched the GPU (devices are counted from the driver's
+    topology, not through HIP): on this pool a process that has initialised HIP may not start a launcher."""
+    import subprocess
+    pkg = graft.load_package()
+    backend = os.environ.get("EBM_BENCH_BACKEND", "nccl")
+    ndev = pkg.visible_gpu_count()
+    if ndev < 1:
+        print("bench.py needs a GPU: the HIP path has no CPU fallback", file=sys.stderr)
+        return 2
+    if backend == "nccl" and ndev < ngpus:
+        print(f"bench.py --gpus {ngpus}: only {ndev} GPU(s) visible on this node — refusing to report an "
+              f"{ngpus}-GPU number from fewer devices (RCCL needs one device per rank; EBM_BENCH_BACKEND=gloo "
+              f"rehearses the N > 1 path with ranks sharing a device and says so in its line)", file=sys.stderr)
+        return 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(pkg.free_port()),
+           os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)       # stderr passes through
+    relayed = 0
+    for line in proc.stdout.splitlines():
+        is_line = False
+        if line.startswith("{"):
+            try:
+                is_line = "metric" in json.loads(line)
+            except ValueError:
+                pass
+        if is_line and not relayed:
+            print(line, flush=True)
+            relayed += 1
+        elif line.strip():
+            print(line, file=sys.stderr)
+    if proc.returncode == 0 and relayed != 1:
+        print("bench.py: the ranks finished without printing the result line", file=sys.stderr)
+        return 3
+    return proc.returncode
+
+
+def kernel_name(model, K, info):
+    """The kernel a workload's launches run, derived the way ebm_run_fused decides (csrc/ebm_runtime.hip)."""
+    if not model.startswith("MIZ"):
+        return "classic_step_kernel"
+    fused_limit = 768 if info["cells_per_thread"] == 2 else 512
+    return "miz_fused_kernel" if (K > 1 and model == "MIZ" and info["threads"] <= fused_limit) else "miz_step_kernel"
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs of this node to run on (one rank each); default: the launcher's world size, else 1")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=5, help="timed blocks of --steps steps; the median is reported")
@@ -126,16 +191,30 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
     args = ap.parse_args()
 
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and (args.gpus or 1) > 1:
+        # no launcher: become one — before anything in this process touches the GPU
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus is None:
+        args.gpus = world
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} under a launcher with WORLD_SIZE={world}: the two must agree "
+                         "(n_gpus in the result line is the number of ranks that really ran)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # one rank per GPU; EBM_BENCH_BACKEND=gloo lets several ranks share a device to rehearse the
     # N > 1 path on a one-GPU box (RCCL refuses two ranks on one device)
     backend = os.environ.get("EBM_BENCH_BACKEND", "nccl")
-    device = local_rank % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev} GPU(s) visible — RCCL needs one device per rank; "
+                         "refusing to report an N-GPU number from fewer devices")
+    device = local_rank % ndev
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
@@ -149,7 +228,10 @@ def main():
     wl = WORKLOADS[args.workload]
     model, kind, nlat, ncol, nt = wl
     integrate = args.workload.endswith("_integrate")
+    every_step_diag = args.workload.endswith("_step")        # step! semantics: all ten variables written every step
     K = max(1, args.steps_per_launch)
+    if every_step_diag and K != 1:
+        raise SystemExit("--workload miz_4096x2048_step is one ebm_step per step: --steps-per-launch must be 1")
     st = pkg.SpaceTime(kind, nlat, nt, 1)
     par = pkg.default_parameters("MIZ" if model.startswith("MIZ") else model)
     lon = np.arange(ncol) + rank * ncol                      # this rank's block of columns
@@ -180,6 +262,13 @@ def main():
             i0 = clock["step"] % nt
             eng.set_time_table(np.take(st.t, np.arange(i0, i0 + n) % nt))
             eng.integrate(n, 1, None, True, 0, 0, MIZ_VARS, want_raw=False, want_seasonal=False, want_avg=True)
+        elif every_step_diag:
+            # Infrastructure.step! once per step (ebm_step with write_diag = 1): the reference's operator returns
+            # Tw, Ti, n, E, T with the prognostics on every call (src/miz.jl:150-196)
+            eng.set_step_clock(clock["step"])
+            tab = eng.ttab
+            for i in range(clock["step"], clock["step"] + n):
+                eng.step(float(tab[i % nt]), float(tab[(i + 1) % nt]), 0.0, True)
         else:
             eng.run(clock["step"], n, None, False, steps_per_launch=K)
         clock["step"] += n
@@ -210,7 +299,7 @@ def main():
     eng.sync()
     eng.reset_counters()
 
-    blocks_wall, blocks_ev = [], []
+    blocks_wall, blocks_ev, own_wall = [], [], []
     for _ in range(max(1, args.repeats)):
         barrier()
         t0 = time.perf_counter()
@@ -219,12 +308,22 @@ def main():
         ev_ms = eng.timer_stop()
         barrier()
         elapsed = time.perf_counter() - t0
+        own_wall.append(elapsed)
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         blocks_wall.append(elapsed)
         blocks_ev.append(ev_ms)
+    # every rank's own view of the timed blocks (rank 0 prints them: the MAX above hides who was slow)
+    mine = {"rank": rank, "device": device, "blocks_ms_per_step": [b * 1e3 / args.steps for b in own_wall],
+            "blocks_event_ms_per_step": [b / args.steps for b in blocks_ev]}
+    ranks = [mine]
+    world_seen = 1
+    if dist is not None:
+        world_seen = dist.get_world_size()
+        ranks = [None] * world_seen
+        dist.all_gather_object(ranks, mine)
     cnt = eng.counters()
     info = eng.launch_info()
     elapsed = statistics.median(blocks_wall)
@@ -275,6 +374,17 @@ def main():
     cells = nlat * ncol
     nsaved = len(MIZ_VARS) if integrate else 0
     bpc = (BYTES_PER_CELL_STEP if model.startswith("MIZ") else 32.0) + 16.0 * nsaved
+    if every_step_diag:
+        bpc += 48.0                                          # T0 and Tw, Ti, n, E, T written as well (144 B, SURVEY 8(d): 136 + T0)
+    spl = (cnt["steps"] / cnt["launches"]) if cnt["launches"] else 1.0
+    kname = kernel_name(model, K, info)
+    fused_note = None
+    if spl > 1.0 and kname != "miz_step_kernel":
+        # K steps per launch with the state in registers: HBM is touched once per LAUNCH, so the algorithmic bytes per
+        # cell-step are 1/K of the per-step figure; the kernel is bound by one workgroup's VALU issue and barrier chain
+        bpc = bpc / spl
+        fused_note = ("fused-K: the state stays in registers between the steps of a launch; achieved/frac count the bytes "
+                      "really moved (per-step figure / K) — this kernel is VALU-issue and barrier-latency bound, not HBM bound")
     launches = cnt["launches"] / max(1, args.repeats)        # kernel launches per timed block
     ev_kernel_ms = max(ev_ms - (year_end_ms or 0.0), 1e-9)   # the step launches alone (integrate: without the year end)
     launch_s = ev_kernel_ms * 1e-3 / max(1.0, launches)
@@ -297,6 +407,9 @@ def main():
         "value": cells * world * args.steps / elapsed,
         "unit": "grid-cell-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "backend": (backend if world > 1 else None), "world_size_seen": world_seen,
+        "devices_used": len({r["device"] for r in ranks}),
+        "ranks": ranks,
         "ms_per_step": elapsed * 1e3 / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
@@ -314,9 +427,10 @@ def main():
                         f"{kind} grid, nt={nt}, {args.spinup} spin-up steps from zero state, "
                         + ("f[member]=-2+4*member/255" if args.workload.startswith("miz_1024x512x32")
                            else ("f=0" if ncol == 1 else "f[lon]=0.5*sin(2*pi*lon/nlon)"))
+                        + (", every step through ebm_step with write_diag = 1 (T0 + Tw, Ti, n, E, T written too)" if every_step_diag else "")
                         + (", ebm_integrate: annual-mean sums of 10 variables from the step kernel's registers, "
                            "means copied out at the end of every block" if integrate else ""),
-            "steps_per_launch": (cnt["steps"] / cnt["launches"]) if cnt["launches"] else None,
+            "steps_per_launch": spl if cnt["launches"] else None,
             "ice_covered_fraction": ice_fraction,
             "mean_tridiagonal_solves_per_column_step": (cnt["solves"] / (cnt["steps"] * ncol)) if model.startswith("MIZ") and cnt["steps"] else 1.0,
             "t0_cap_hits": cnt["cap_hits"],
@@ -327,7 +441,7 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": ("miz_fused_kernel" if K > 1 and info["threads"] <= 512 else "miz_step_kernel") if model.startswith("MIZ") else "classic_step_kernel",
+            "kernel": kname, **({"note": fused_note} if fused_note else {}),
             "algorithmic_bytes_per_cell_step": bpc,
             "algorithmic_bytes_per_launch": bpc * cells * cnt["steps"] / max(1, cnt["launches"]),
             "avg_launch_ms": launch_s * 1e3,

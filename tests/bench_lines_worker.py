@@ -21,5 +21,15 @@ for args in RUNS:
 r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "hysteresis_ensemble.py"), "--members", "8", "--nlat", "90", "--nt", "500"],
                    capture_output=True, text=True, cwd=ROOT)
 out.append({"args": ["hysteresis_ensemble.py"], "rc": r.returncode, "stdout": r.stdout, "stderr_tail": r.stderr[-600:]})
+# bench.py --gpus 2 without a launcher: the parent starts the two ranks itself.  On this one-GPU box (a) the default
+# backend (RCCL) must refuse loudly — two ranks cannot share a device, and an N-GPU number is never reported from fewer
+# devices; (b) EBM_BENCH_BACKEND=gloo rehearses the N > 1 path with both ranks on the one GPU and says so in its line.
+two = ["--gpus", "2", "--workload", "miz_1024x512x32", "--steps", "10", "--repeats", "2", "--spinup", "50", "--preroll", "0.02", "--cpu-budget", "0"]
+for backend in ("nccl", "gloo"):
+    env = dict(os.environ, EBM_BENCH_BACKEND=backend)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + two, capture_output=True, text=True, cwd=ROOT, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    out.append({"args": two, "backend": backend, "rc": r.returncode, "nlines": len(lines),
+                "line": json.loads(lines[-1]) if lines and r.returncode == 0 else None, "stderr_tail": r.stderr[-1500:]})
 with open(sys.argv[1], "w") as fh:
     json.dump(out, fh)

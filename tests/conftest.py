@@ -31,11 +31,9 @@ def pytest_sessionstart(session):
     markexpr = session.config.getoption("-m") or ""
     if "gpu" not in markexpr or "not gpu" in markexpr:
         return
-    try:
-        import torch
-        if torch.cuda.device_count() < 1:          # counting devices does not initialise the GPU
-            return
-    except Exception:
+    # is there a GPU?  Asked of the kernel driver's topology, not of torch / HIP: this process must not have
+    # initialised the GPU when it starts the children below (energybalancemodel.jl_amd/_devices.py)
+    if graft.load_package().visible_gpu_count() < 1:
         return
     tmp = tempfile.mkdtemp(prefix="ebm_two_rank_")
     TWO_RANK["out"] = os.path.join(tmp, "gathered.npz")
@@ -58,7 +56,7 @@ def pytest_sessionstart(session):
     with open(TWO_RANK["log"], "w") as log:
         TWO_RANK["proc"] = subprocess.Popen(
             [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-             "--master-addr", "127.0.0.1", "--master-port", "29541",
+             "--master-addr", "127.0.0.1", "--master-port", str(graft.load_package().free_port()),
              os.path.join(ROOT, "tests", "two_rank_worker.py"), TWO_RANK["out"]],
             env=env, stdout=log, stderr=subprocess.STDOUT)
 

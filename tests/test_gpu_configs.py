@@ -363,6 +363,7 @@ def test_bench_lines_are_self_consistent(pkg):
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                   "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
             assert k in d, (i, k)
+        assert d["world_size_seen"] == 1 and d["devices_used"] == 1 and len(d["ranks"]) == 1
         assert d["unit"] == "grid-cell-steps/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
         assert d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None and "workload" in d["config"]
         assert d["steps"] == int(r["args"][r["args"].index("--steps") + 1])
@@ -384,8 +385,43 @@ def test_bench_lines_are_self_consistent(pkg):
     assert cb and cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "grid-cell-steps/s" and cb["sample"]
     assert all(r["line"]["cpu_baseline"] is None for r in runs[1:])
     assert "fused" in fused["metric"] and fused["config"]["steps_per_launch"] == 16.0 and fused["roofline"]["kernel"] == "miz_fused_kernel"
+    # fused-K: HBM is touched once per launch, the line counts the bytes really moved (96 / K per cell-step) and says so
+    assert fused["roofline"]["algorithmic_bytes_per_cell_step"] == 96.0 / 16.0 and "fused-K" in fused["roofline"]["note"]
     assert integ["roofline"]["algorithmic_bytes_per_cell_step"] == 256.0 and integ["year_end_ms"] >= 0.0
     assert classic["roofline"]["algorithmic_bytes_per_cell_step"] == 32.0 and classic["roofline"]["kernel"] == "classic_step_kernel"
+
+
+def test_bench_gpus_n_starts_n_ranks(pkg):
+    """`python bench.py --gpus 2` with no launcher (what a driver types): the parent — which has made no GPU call —
+    starts two ranks as a child process group and relays rank 0's line.  On a one-GPU box the default backend (RCCL)
+    refuses loudly instead of reporting a two-GPU number from one device; with EBM_BENCH_BACKEND=gloo the two ranks share
+    the GPU and the line says n_gpus = 2, world size 2, backend gloo, one device, every rank's own block timings, and
+    value = the cells of BOTH ranks x steps / the slowest rank's time.  (Started by conftest's child.)"""
+    import json
+    import torch
+    proc = conftest.BENCH_LINES["proc"]
+    if proc is None:
+        pytest.skip("bench child not started (no -m gpu session start)")
+    assert proc.wait(timeout=900) == 0
+    runs = json.load(open(conftest.BENCH_LINES["out"]))
+    nccl, gloo = runs[5], runs[6]
+    assert nccl["backend"] == "nccl" and gloo["backend"] == "gloo"
+    if torch.cuda.device_count() < 2:
+        assert nccl["rc"] != 0 and nccl["nlines"] == 0, nccl
+        assert "only 1 GPU(s) visible" in nccl["stderr_tail"] and "refusing" in nccl["stderr_tail"]
+    else:
+        assert nccl["rc"] == 0 and nccl["line"]["n_gpus"] == 2 and nccl["line"]["devices_used"] == 2, nccl["stderr_tail"]
+    assert gloo["rc"] == 0 and gloo["nlines"] == 1, gloo["stderr_tail"]
+    d = gloo["line"]
+    assert d["n_gpus"] == 2 and d["world_size_seen"] == 2 and d["backend"] == "gloo" and d["scaling"] == "weak"
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and all(len(r["blocks_ms_per_step"]) == d["repeats"] for r in d["ranks"])
+    assert d["devices_used"] == len({r["device"] for r in d["ranks"]}) <= torch.cuda.device_count()
+    cells = 1024 * 16384
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (2 * cells) - 1.0) < 1e-9       # whole-job throughput: both ranks' cells
+    # every reported block is the MAX over the ranks of that block
+    for i, b in enumerate(d["blocks_ms_per_step"]):
+        assert abs(b - max(r["blocks_ms_per_step"][i] for r in d["ranks"])) < 1e-9 * b
+    assert "32" in d["config"]["workload"] and "f[member]" in d["config"]["workload"]
 
 
 def test_hysteresis_example_runs(pkg):

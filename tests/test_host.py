@@ -379,3 +379,38 @@ def test_integration_doc_lists_every_exported_symbol():
     assert len(syms) >= 27
     missing = [s for s in syms if not re.search(r"\b" + s + r"\b", doc)]
     assert not missing, missing
+
+
+def test_bench_gpus_n_refuses_without_devices():
+    """`python bench.py --gpus 2` on a machine with fewer than two GPUs exits non-zero and says why — it never runs
+    one GPU and reports it as two (here: no GPU at all; on the GPU box tests/test_gpu_configs.py checks the one-GPU
+    case and the two-rank rehearsal).  `--gpus` that disagrees with a launcher's world size is refused as well."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "GPU" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "must agree" in r.stderr and r.stdout.strip() == ""
+
+
+def test_visible_gpu_count_reads_the_driver_topology(pkg, tmp_path, monkeypatch):
+    """Launch decisions count GPUs without initialising HIP: KFD topology nodes with SIMDs, narrowed by the
+    *_VISIBLE_DEVICES variables the runtime honours."""
+    dev = pkg._devices if hasattr(pkg, "_devices") else __import__("sys").modules[pkg.__name__ + "._devices"]
+    for i, simd in enumerate((0, 256, 256, 256)):               # node 0: the CPU
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text(f"cpu_cores_count {16 if simd == 0 else 0}\nsimd_count {simd}\n")
+    monkeypatch.setattr(dev, "_KFD_NODES", str(tmp_path / "*" / "properties"))
+    assert dev._kfd_gpu_nodes() == 3
+    assert dev._visible_filter(3, {}) == 3
+    assert dev._visible_filter(3, {"HIP_VISIBLE_DEVICES": "0,2"}) == 2
+    assert dev._visible_filter(3, {"ROCR_VISIBLE_DEVICES": "1", "HIP_VISIBLE_DEVICES": "0,1,2"}) == 1
+    assert dev._visible_filter(3, {"HIP_VISIBLE_DEVICES": ""}) == 0
+    if not os.path.exists("/dev/kfd"):
+        assert pkg.visible_gpu_count() == 0
+    port = pkg.free_port()
+    assert 1024 < port < 65536
