@@ -3,7 +3,7 @@
 Host-side mirror of the reference's ``step!`` / ``integrate`` surface over hand-written HIP
 kernels reached through the C ABI of ``include/ebm_hip.h``.  See DESIGN.md.
 """
-from ._lib import EBMError, LIB_PATH, EXPORTS  # noqa: F401
+from ._lib import EBMError, StaleFieldError, LIB_PATH, EXPORTS  # noqa: F401
 from ._devices import visible_gpu_count, free_port  # noqa: F401
 from .engine import Engine, cos2pit  # noqa: F401
 from .infrastructure import (  # noqa: F401

@@ -23,7 +23,7 @@ FIELD = {"Ei": 0, "Ew": 1, "h": 2, "D": 3, "phi": 4, "T0": 5, "Tw": 6, "Ti": 7, 
 PARAM_ORDER = ("D", "A", "B", "cw", "S0", "S1", "S2", "a0", "a2", "ai", "Fb", "k", "Lf", "F",
                "cg", "tau", "Tm", "m1", "m2", "alpha", "rl", "Dmin", "Dmax", "hmin", "kappa")
 EXPORTS = (
-    "ebm_create", "ebm_destroy", "ebm_last_error", "ebm_version", "ebm_set_field",
+    "ebm_create", "ebm_create_ex", "ebm_options_default", "ebm_field_step", "ebm_get_field_as_of", "ebm_destroy", "ebm_last_error", "ebm_version", "ebm_set_field",
     "ebm_get_field", "ebm_hemispheric_mean", "ebm_hemispheric_mean_device", "ebm_get_field_device",
     "ebm_field_device_ptr", "ebm_diffusion", "ebm_set_column_forcing", "ebm_set_column_schedule",
     "ebm_set_step_clock", "ebm_set_time_table",
@@ -35,9 +35,23 @@ EXPORTS = (
 _dp = C.POINTER(C.c_double)
 _lib = None
 
+STATUS = {0: "EBM_OK", -1: "EBM_ERR_ARG", -2: "EBM_ERR_HIP", -3: "EBM_ERR_UNSUPPORTED", -4: "EBM_ERR_NO_DEVICE",
+          -5: "EBM_ERR_STALE"}
+
+
+class Options(C.Structure):
+    """struct ebm_options (include/ebm_hip.h)."""
+    _fields_ = [("struct_bytes", C.c_int), ("cells_per_thread", C.c_int), ("use_graph", C.c_int),
+                ("prefetch_cols", C.c_int)]
+
 
 class EBMError(RuntimeError):
-    """A C-ABI call returned a negative ebm_status."""
+    """A C-ABI call returned a negative ebm_status (``.status``)."""
+    status = 0
+
+
+class StaleFieldError(EBMError):
+    """EBM_ERR_STALE: a diagnostic field (or the fp64 T0) older than the state was asked for."""
 
 
 def load():
@@ -63,6 +77,11 @@ def load():
     lib.ebm_version.restype = C.c_char_p
     lib.ebm_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp,
                                C.c_double, C.c_int]
+    lib.ebm_create_ex.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp,
+                                  C.c_double, C.c_int, C.POINTER(Options)]
+    lib.ebm_options_default.argtypes = [C.POINTER(Options)]
+    lib.ebm_field_step.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
+    lib.ebm_get_field_as_of.argtypes = [C.c_void_p, C.c_int, C.c_longlong, _dp]
     lib.ebm_destroy.argtypes = [C.c_void_p]
     lib.ebm_set_field.argtypes = [C.c_void_p, C.c_int, _dp]
     lib.ebm_get_field.argtypes = [C.c_void_p, C.c_int, _dp]
@@ -97,7 +116,9 @@ def load():
 def check(rc: int, what: str):
     if rc != 0:
         msg = load().ebm_last_error().decode()
-        raise EBMError(f"{what} failed (status {rc}): {msg}")
+        err = (StaleFieldError if rc == -5 else EBMError)(f"{what} failed (status {rc} {STATUS.get(rc, '?')}): {msg}")
+        err.status = rc
+        raise err
 
 
 def dptr(a):

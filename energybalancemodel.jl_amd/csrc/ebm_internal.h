@@ -46,8 +46,8 @@ enum OutMode {
     OUT_DIAG = 1,    // + T0 and the diagnostic fields
     OUT_SAVE = 2,    // savesol! fused into the step: annual-mean running sums and/or a raw snapshot
                      // from registers; the diagnostic fields only if write_diag
-    OUT_LOOP = 3,    // nfused steps in one launch (state through L2 between steps, long meridians);
-                     // the diagnostic fields after the last step if write_diag
+    OUT_LOOP = 3,    // nfused steps in one launch, the whole state in registers between them (miz_fused_kernel: meridians of
+                     // up to 2048 cells; classic: any); the diagnostic fields after the last step if write_diag
 };
 
 // Per-latitude constant tables: one slab, table i at geom + i*gstride (gstride = pitch).
@@ -108,8 +108,8 @@ constexpr int kFusedRegThreads = 512;   // up to here the fused-K kernel keeps t
 constexpr int kFusedRegThreads2 = 768;  // ... with 2 cells per thread (168 VGPRs: three waves per SIMD)
 constexpr int kMaxLat2 = 1536;          // longest meridian stepped with 2 cells per thread
 
-// force_cells: 0 = choose (4 cells per thread; 2 for a few short meridians), 2 / 4 = as told
-LaunchCfg choose_launch(int nlat, int ncol, int force_cells);
+// cells_requested: 2 (honoured for nlat <= kMaxLat2) or anything else = 4.  A function of nlat and the request only.
+LaunchCfg choose_launch(int nlat, int cells_requested);
 hipError_t prepare_kernels(const LaunchCfg &cfg);   // raises the dynamic-LDS limit if needed
 // One workgroup per column.  mode: OutMode; OUT_LOOP runs a.nfused steps per launch.
 // The per-step MIZ kernels, one function per build part of ebm_kernels.hip (EBM_PART); nullptr = not compiled
@@ -131,8 +131,12 @@ hipError_t launch_hemispheric_mean(const double *field, const double *x, int pit
 // out = base + D d/dx[(1-x^2) d temp/dx] per column ([ncol][pitch] device arrays; base may be null)
 hipError_t launch_diffusion(const double *temp, const double *base, double *out, const double *geom, long long gstride,
                             const Params *p, int grid_kind, int pitch, int nlat, int ncol, hipStream_t s);
-// annual_mean (src/infrastructure.jl:536-544): dst[col][k] = sum/nt with `sum` in the pair-split
-// layout of the step kernels, then sum = 0
-hipError_t launch_finish_mean(double *dst, double *sum, double nt, int ncol, const LaunchCfg &cfg, hipStream_t s);
+// annual_mean (src/infrastructure.jl:536-544): dst[v][col][k] = sum[v]/nt with `sum` in the pair-split
+// layout of the step kernels, then sum = 0; all nvars variables (var_stride apart) in one launch
+hipError_t launch_finish_mean(double *dst, double *sum, double nt, int ncol, int nvars, long long var_stride,
+                              const LaunchCfg &cfg, hipStream_t s);
+// the diagnostic fields of a 4-cells-per-thread step launch, pair-split -> natural layout, in place
+hipError_t launch_unsplit_fields(double *fields, long long field_stride, int nfields, int ncol, const LaunchCfg &cfg,
+                                 hipStream_t s);
 
 }  // namespace ebm

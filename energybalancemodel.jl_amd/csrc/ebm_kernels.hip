@@ -646,8 +646,10 @@ __device__ __forceinline__ void save_pair(const StepArgs &a, size_t col_off, uns
 // meridian, (I - (dt/cw)*Dif) dE_new = dE — the same partition + cyclic reduction as the T0 system — and the
 // diffusion term of both vertical fluxes is corrected by (dE_new - dE)/dt.  Lifts the explicit limit
 // dt <= cw*dx^2/(2D) of the reference's step.
+// __launch_bounds__(TT, 4): the workgroup size is the compile-time TT, never more; four waves per SIMD keep the
+// 128-VGPR budget that lets a 1024-thread workgroup (and four 256-thread ones) share a CU.
 template <int C, int GRID, int OUT, int TT, bool IMEX>
-__global__ void __launch_bounds__(1024) miz_step_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(TT, 4) miz_step_kernel(const StepArgs a) {
     static_assert(C == 2 || C == 4, "cells per thread");
     static_assert(OUT == OUT_STATE || OUT == OUT_DIAG || OUT == OUT_SAVE, "per-step kernel");
     constexpr bool MAYDIAG = OUT != OUT_STATE;            // diagnostic stores compiled in
@@ -942,16 +944,20 @@ __global__ void __launch_bounds__(1024) miz_step_kernel(const StepArgs a) {
 #undef EBM_PUT4
         }
         if (MAYDIAG && diag) {
-            // The diagnostic fields go out pair by pair, i.e. as the two halves of each lane's 32-byte sector ~10^4 cycles
-            // apart (no LDS is left to park five more fields).  With the default cache policy L2 often still holds the first
-            // half when the second arrives and writes the sector once: 0.360 vs 0.393 ms for a diagnostic step of the
-            // 4096 x 2048 shape with non-temporal stores here (state-only step: 0.164).
+            // The diagnostic fields are outputs only: they are stored in the PAIR-SPLIT layout (pair j of thread t at
+            // j*2T + 2t, the layout of the annual-mean sums), in which every store instruction of a wave covers whole
+            // 128-B lines — stored in the natural layout they left pair by pair, i.e. as the two halves of each lane's
+            // 32-byte sector ~10^4 cycles apart (no LDS is left to park five more fields): 0.36 ms for a diagnostic step
+            // of the 4096 x 2048 shape against 0.164 state-only.  The runtime un-permutes in place before the first
+            // read (unsplit_fields_kernel; ebm_ctx::diag_split).  With two cells per thread the pair IS the chunk and
+            // the two layouts coincide.
+            const unsigned ks = (unsigned)(j * 2 * T + 2 * t);
 #define EBM_PUTP(slot_, qi)                                                                        \
             {                                                                                      \
                 double2 d_;                                                                        \
                 d_.x = v0 ? o[0].q[qi] : 0.0;                                                      \
                 d_.y = v1 ? o[1].q[qi] : 0.0;                                                      \
-                *reinterpret_cast<double2 *>(st + (slot_) * a.fstride + kp) = d_;                  \
+                EBM_STORE2(st + (slot_) * a.fstride + ks, d_);                                     \
             }
             EBM_PUTP(S_n, Q_n) EBM_PUTP(S_E, Q_E) EBM_PUTP(S_T, Q_T) EBM_PUTP(S_Ti, Q_Ti) EBM_PUTP(S_Tw, Q_Tw)
 #undef EBM_PUTP
@@ -1280,11 +1286,12 @@ hipError_t launch_diffusion(const double *temp, const double *base, double *out,
 }
 
 // annual_mean (src/infrastructure.jl:536-544, crossmean src/utilities.jl:390-395): sum / nt, from
-// the pair-split layout of save_pair to the natural [col][pitch] one; the sum restarts at zero.
+// the pair-split layout of save_pair to the natural [col][pitch] one; the sum restarts at zero.  blockIdx.y = saved
+// variable (one launch for all of them): dst / sum advance by var_stride per variable.
 __global__ void finish_mean_kernel(double *__restrict__ dst, double *__restrict__ sum, double nt, int threads,
-                                   int cells) {
+                                   int cells, long long var_stride) {
     const int t = threadIdx.x, col = blockIdx.x;
-    const size_t base = (size_t)col * (size_t)threads * cells;
+    const size_t base = (size_t)blockIdx.y * (size_t)var_stride + (size_t)col * (size_t)threads * cells;
     for (int j = 0; j < cells / 2; ++j) {
         double2 *sp = reinterpret_cast<double2 *>(sum + base + (size_t)(j * 2 * threads + 2 * t));
         const double2 s = *sp;
@@ -1299,19 +1306,40 @@ __global__ void finish_mean_kernel(double *__restrict__ dst, double *__restrict_
     }
 }
 
+// Pair-split -> natural layout, in place: the diagnostic fields as the 4-cells-per-thread step kernels store them
+// (pair j of thread t at j*2T + 2t) become [col][pitch] with cell k at k.  One workgroup per column holds the whole
+// column in registers across a barrier, so the permutation needs no second buffer.  blockIdx.y = field: `fields`
+// advances by field_stride per field.
+__global__ void unsplit_fields_kernel(double *__restrict__ fields, long long field_stride, int threads) {
+    const int t = threadIdx.x;
+    double *f = fields + (size_t)blockIdx.y * (size_t)field_stride + (size_t)blockIdx.x * (size_t)threads * 4;
+    const double2 p0 = *reinterpret_cast<const double2 *>(f + 2 * t);
+    const double2 p1 = *reinterpret_cast<const double2 *>(f + 2 * threads + 2 * t);
+    __syncthreads();
+    *reinterpret_cast<double2 *>(f + 4 * t) = p0;
+    *reinterpret_cast<double2 *>(f + 4 * t + 2) = p1;
+}
+hipError_t launch_unsplit_fields(double *fields, long long field_stride, int nfields, int ncol, const LaunchCfg &cfg,
+                                 hipStream_t s) {
+    if (cfg.cells != 4) return hipSuccess;               // two cells per thread: the layouts coincide
+    unsplit_fields_kernel<<<dim3(ncol, nfields), cfg.threads, 0, s>>>(fields, field_stride, cfg.threads);
+    return hipGetLastError();
+}
+
 // ---- host-side launchers ----------------------------------------------------------------------
-// Cells per thread.  4 everywhere that throughput matters (32 contiguous bytes per lane and field).
-// A run of a few short meridians is latency-bound on a handful of waves: there 2 cells per thread put
-// twice as many SIMDs to work on every meridian (nlat <= kMaxLat2 = 1536: the fused kernel then still fits three waves per SIMD).
-LaunchCfg choose_launch(int nlat, int ncol, int force_cells) {
+// Cells per thread: 4 unless the caller asks for 2 (ebm_options::cells_per_thread; nlat <= kMaxLat2 = 1536: the
+// fused kernel then still fits three waves per SIMD).  4 is the throughput geometry (32 contiguous bytes per lane and
+// field); a run of a FEW short meridians is latency-bound on a handful of waves, and 2 cells per thread put twice as
+// many SIMDs to work on every meridian.  The geometry — and with it the tridiagonal partition, i.e. the rounding of the
+// solves — is a function of (nlat, cells) ONLY, never of the number of columns: a member gives the same bits alone, in
+// a large ensemble and under any sharding.
+LaunchCfg choose_launch(int nlat, int cells_requested) {
     LaunchCfg cfg{};
     if (nlat > kMaxLat) {
         cfg.threads = 0;
         return cfg;
     }
-    int cells = 4;
-    if (nlat <= kMaxLat2 && (long long)ncol * ((nlat + 255) / 256) <= 128) cells = 2;
-    if ((force_cells == 2 && nlat <= kMaxLat2) || force_cells == 4) cells = force_cells;
+    const int cells = (cells_requested == 2 && nlat <= kMaxLat2) ? 2 : 4;
     const int chunks = (nlat + cells - 1) / cells;
     cfg.threads = ((chunks + 63) / 64) * 64;
     if (cells == 2 && cfg.threads > 512) cfg.threads = 768;     // the one size compiled beyond 512 (padding cells stay zero)
@@ -1471,8 +1499,9 @@ hipError_t launch_hemispheric_mean(const double *field, const double *x, int pit
     hemispheric_mean_kernel<<<ncol, 256, sizeof(double) * (size_t)nlat, s>>>(field, x, pitch, nlat, out);
     return hipGetLastError();
 }
-hipError_t launch_finish_mean(double *dst, double *sum, double nt, int ncol, const LaunchCfg &cfg, hipStream_t s) {
-    finish_mean_kernel<<<ncol, cfg.threads, 0, s>>>(dst, sum, nt, cfg.threads, cfg.cells);
+hipError_t launch_finish_mean(double *dst, double *sum, double nt, int ncol, int nvars, long long var_stride,
+                              const LaunchCfg &cfg, hipStream_t s) {
+    finish_mean_kernel<<<dim3(ncol, nvars), cfg.threads, 0, s>>>(dst, sum, nt, cfg.threads, cfg.cells, var_stride);
     return hipGetLastError();
 }
 #endif  // EBM_PART_MAIN

@@ -3,11 +3,17 @@
 // ebm_kernels.hip.  There is deliberately no CPU fallback: without a GPU every entry point
 // fails with EBM_ERR_NO_DEVICE.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ebm_hip.h"
@@ -30,6 +36,250 @@ int fail(int code, const std::string &msg) {
         if (e_ != hipSuccess)                                                              \
             return fail(EBM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
     } while (0)
+
+// ---- host transfers: pinned staging ring + a few host threads ---------------------------------------
+// The caller's buffers are pageable.  A device -> pageable copy through the runtime alone runs at 7-8 GB/s
+// (one thread faults the destination's pages in and copies); here the DMA engine fills a pinned slot while
+// the previous slot is copied on to the caller's buffer by kCopyThreads host threads.
+
+// Process-wide pool: parallel_for(n, fn) runs fn(i) for i in [0, n) on the pool's threads and returns when
+// all are done.  One caller at a time (callers serialise on `gate`).
+class HostPool {
+public:
+    static HostPool &get() {
+        static HostPool *pool = new HostPool();      // never destroyed: its threads sleep until the process ends
+        return *pool;
+    }
+    int size() const { return (int)threads_.size(); }
+    void parallel_for(int n, const std::function<void(int)> &fn) {
+        if (n <= 0) return;
+        std::lock_guard<std::mutex> one(gate_);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn;
+            next_ = 0;
+            total_ = n;
+            left_ = n;
+            ++generation_;
+        }
+        cv_.notify_all();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return left_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    HostPool() {
+        unsigned hw = std::thread::hardware_concurrency();
+        int n = (int)std::min(8u, std::max(1u, hw));
+        for (int i = 0; i < n; ++i) threads_.emplace_back([this] { run(); }), threads_.back().detach();
+    }
+    void run() {
+        unsigned long long seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [&] { return generation_ != seen; });
+            seen = generation_;
+            while (next_ < total_) {
+                const int i = next_++;
+                const std::function<void(int)> *fn = fn_;
+                lk.unlock();
+                (*fn)(i);
+                lk.lock();
+                if (--left_ == 0) done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex gate_, m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(int)> *fn_ = nullptr;
+    int next_ = 0, total_ = 0, left_ = 0;
+    unsigned long long generation_ = 0;
+};
+
+// contiguous copy split over the pool (pieces of >= 1 MiB)
+void parallel_memcpy(void *dst, const void *src, size_t bytes) {
+    HostPool &pool = HostPool::get();
+    const size_t piece = std::max<size_t>((size_t)1 << 20, (bytes + pool.size() * 4 - 1) / (pool.size() * 4));
+    const int n = (int)((bytes + piece - 1) / piece);
+    if (n <= 1) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    pool.parallel_for(n, [&](int i) {
+        const size_t off = (size_t)i * piece;
+        std::memcpy((char *)dst + off, (const char *)src + off, std::min(piece, bytes - off));
+    });
+}
+
+constexpr int kRingSlots = 4;
+constexpr size_t kSlotBytes = (size_t)16 << 20;
+
+// One device -> host copy: nrows rows of row_elems doubles, src_pitch elements apart on the device, packed on the host.
+struct CopyJob {
+    const double *src = nullptr;
+    size_t src_pitch = 0, row_elems = 0, nrows = 0;
+    double *dst = nullptr;
+};
+
+// The handle's copier: a pinned ring, a copy stream and (for the asynchronous jobs of ebm_integrate) a worker
+// thread that runs the jobs in order while the caller keeps launching steps.
+struct HostCopier {
+    int device = 0;
+    char *ring = nullptr;                           // kRingSlots x kSlotBytes, pinned
+    hipStream_t stream = nullptr;                   // DMA stream (ordered after the compute stream by ev_ready)
+    hipEvent_t slot_ev[kRingSlots] = {nullptr};
+    hipEvent_t ev_ready = nullptr;
+    std::thread worker;
+    std::mutex m;
+    std::condition_variable cv, idle;
+    std::deque<CopyJob> q;
+    bool stop = false, busy = false;
+    hipError_t err = hipSuccess;
+
+    hipError_t init(int dev) {
+        device = dev;
+        hipError_t e = hipHostMalloc((void **)&ring, kRingSlots * kSlotBytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+        for (int i = 0; i < kRingSlots && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&slot_ev[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming);
+        return e;
+    }
+    void shutdown() {
+        if (worker.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(m);
+                stop = true;
+            }
+            cv.notify_all();
+            worker.join();
+        }
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (auto &ev : slot_ev)
+            if (ev) (void)hipEventDestroy(ev);
+        if (ev_ready) (void)hipEventDestroy(ev_ready);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (ring) (void)hipHostFree(ring);
+        ring = nullptr;
+        stream = nullptr;
+        ev_ready = nullptr;
+        for (auto &ev : slot_ev) ev = nullptr;
+    }
+    // everything the compute stream has been given so far happens before the copies submitted from now on
+    hipError_t order_after(hipStream_t compute) {
+        hipError_t e = hipEventRecord(ev_ready, compute);
+        if (e == hipSuccess) e = hipStreamWaitEvent(stream, ev_ready, 0);
+        return e;
+    }
+    // device -> pinned slot -> caller's buffer, the DMA of piece i+1.. in flight while piece i is copied on
+    hipError_t run(const CopyJob &j) {
+        if (j.nrows == 0 || j.row_elems == 0) return hipSuccess;
+        const size_t row_bytes = sizeof(double) * j.row_elems;
+        const bool packed = j.src_pitch == j.row_elems;
+        // pieces: whole rows when a row fits a slot, else slices of one row
+        const size_t rows_per = std::max<size_t>(1, kSlotBytes / row_bytes);
+        const size_t slices = row_bytes > kSlotBytes ? (row_bytes + kSlotBytes - 1) / kSlotBytes : 1;
+        const size_t npieces = slices > 1 ? j.nrows * slices : (j.nrows + rows_per - 1) / rows_per;
+        auto piece = [&](size_t i, const char *&src, char *&dst, size_t &nr, size_t &bytes_per_row) {
+            if (slices > 1) {
+                const size_t r = i / slices, sl = i % slices, off = sl * kSlotBytes;
+                src = (const char *)(j.src + r * j.src_pitch) + off;
+                dst = (char *)(j.dst + r * j.row_elems) + off;
+                nr = 1;
+                bytes_per_row = std::min(kSlotBytes, row_bytes - off);
+            } else {
+                const size_t r0 = i * rows_per;
+                src = (const char *)(j.src + r0 * j.src_pitch);
+                dst = (char *)(j.dst + r0 * j.row_elems);
+                nr = std::min(rows_per, j.nrows - r0);
+                bytes_per_row = row_bytes;
+            }
+        };
+        auto issue = [&](size_t i) -> hipError_t {
+            const char *src; char *dst; size_t nr, bpr;
+            piece(i, src, dst, nr, bpr);
+            char *slot = ring + (i % kRingSlots) * kSlotBytes;
+            hipError_t e = (packed || nr == 1)
+                ? hipMemcpyAsync(slot, src, nr * bpr, hipMemcpyDeviceToHost, stream)
+                : hipMemcpy2DAsync(slot, bpr, src, sizeof(double) * j.src_pitch, bpr, nr, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipEventRecord(slot_ev[i % kRingSlots], stream);
+            return e;
+        };
+        hipError_t e = hipSuccess;
+        for (size_t i = 0; i < std::min<size_t>(kRingSlots - 1, npieces) && e == hipSuccess; ++i) e = issue(i);
+        for (size_t i = 0; i < npieces && e == hipSuccess; ++i) {
+            if (i + kRingSlots - 1 < npieces) e = issue(i + kRingSlots - 1);      // its slot was drained at piece i-1
+            if (e == hipSuccess) e = hipEventSynchronize(slot_ev[i % kRingSlots]);
+            if (e != hipSuccess) break;
+            const char *src; char *dst; size_t nr, bpr;
+            piece(i, src, dst, nr, bpr);
+            parallel_memcpy(dst, ring + (i % kRingSlots) * kSlotBytes, nr * bpr);
+        }
+        if (e != hipSuccess) (void)hipStreamSynchronize(stream);
+        return e;
+    }
+    // caller's buffer -> pinned slot -> device
+    hipError_t upload(double *dst_dev, size_t dst_pitch, const double *src, size_t row_elems, size_t nrows) {
+        const size_t row_bytes = sizeof(double) * row_elems;
+        if (row_bytes > kSlotBytes)      // (a single row beyond a slot: not a shape this library has — keep it simple)
+            return hipMemcpy2D(dst_dev, sizeof(double) * dst_pitch, src, row_bytes, row_bytes, nrows, hipMemcpyHostToDevice);
+        const size_t rows_per = std::max<size_t>(1, kSlotBytes / row_bytes);
+        const size_t npieces = (nrows + rows_per - 1) / rows_per;
+        hipError_t e = hipSuccess;
+        for (size_t i = 0; i < npieces && e == hipSuccess; ++i) {
+            const size_t r0 = i * rows_per, nr = std::min(rows_per, nrows - r0);
+            char *slot = ring + (i % kRingSlots) * kSlotBytes;
+            if (i >= kRingSlots) e = hipEventSynchronize(slot_ev[i % kRingSlots]);      // the slot's previous DMA has read it
+            if (e != hipSuccess) break;
+            parallel_memcpy(slot, src + r0 * row_elems, nr * row_bytes);
+            e = (dst_pitch == row_elems)
+                ? hipMemcpyAsync(dst_dev + r0 * dst_pitch, slot, nr * row_bytes, hipMemcpyHostToDevice, stream)
+                : hipMemcpy2DAsync(dst_dev + r0 * dst_pitch, sizeof(double) * dst_pitch, slot, row_bytes, row_bytes, nr,
+                                   hipMemcpyHostToDevice, stream);
+            if (e == hipSuccess) e = hipEventRecord(slot_ev[i % kRingSlots], stream);
+        }
+        hipError_t e2 = hipStreamSynchronize(stream);
+        return e != hipSuccess ? e : e2;
+    }
+    // asynchronous jobs (ebm_integrate): queued, run in order by the worker thread
+    void submit(const CopyJob &j) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (!worker.joinable()) worker = std::thread([this] { loop(); });
+            q.push_back(j);
+        }
+        cv.notify_all();
+    }
+    hipError_t wait_all() {
+        std::unique_lock<std::mutex> lk(m);
+        idle.wait(lk, [&] { return q.empty() && !busy; });
+        hipError_t e = err;
+        err = hipSuccess;
+        return e;
+    }
+    void loop() {
+        (void)hipSetDevice(device);
+        for (;;) {
+            CopyJob j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                j = q.front();
+                q.pop_front();
+                busy = true;
+            }
+            hipError_t e = run(j);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (e != hipSuccess && err == hipSuccess) err = e;
+                busy = false;
+            }
+            idle.notify_all();
+        }
+    }
+};
 
 }  // namespace
 
@@ -65,6 +315,20 @@ struct ebm_ctx {
     long long n_steps = 0, n_launches = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Validity of the fields that only some steps write (diagnostics, the fp64 T0): `epoch` counts every change
+    // of the prognostic state (steps taken, prognostic fields overwritten), `state_step` is the global index of
+    // the last step taken (-1: none); a field is current iff written_epoch[f] == epoch.
+    long long epoch = 0, state_step = -1;
+    long long written_epoch[EBM_F_COUNT], written_step[EBM_F_COUNT];
+    // The MIZ step kernels (4 cells per thread) store the five diagnostic fields in the pair-split layout (whole
+    // 128-B lines per store instruction, csrc/ebm_kernels.hip); whoever reads one of them gets the natural layout:
+    // the first reader after such a step runs the in-place un-permutation once.
+    bool diag_split = false;
+    HostCopier *copier = nullptr;                  // pinned staging ring, lazily created by the first host transfer
+    double *scratch = nullptr;                     // ebm_diffusion: temp | base | out, kept between calls
+    // ebm_integrate's device buffers, kept between calls while the shape stays the same
+    double *ig_sums = nullptr, *ig_mean = nullptr, *ig_snap = nullptr, *ig_stage = nullptr, *ig_hm = nullptr;
+    size_t ig_sums_n = 0, ig_mean_n = 0, ig_snap_n = 0, ig_stage_n = 0, ig_hm_n = 0;
 };
 
 namespace {
@@ -81,6 +345,39 @@ int slot_of(int model, int f) {
     }
 }
 bool has_field(const ebm_ctx *h, int f) { return f >= 0 && f < EBM_F_COUNT && slot_of(h->model, f) >= 0; }
+
+// fields that only diagnostic steps write (everything else is prognostic and always current)
+bool is_diagnostic(const ebm_ctx *h, int f) {
+    if (h->model == EBM_MODEL_MIZ)
+        return f == EBM_F_T0 || f == EBM_F_Tw || f == EBM_F_Ti || f == EBM_F_n || f == EBM_F_E || f == EBM_F_T;
+    return f == EBM_F_T || f == EBM_F_h;
+}
+const char *field_name(int f) {
+    static const char *names[EBM_F_COUNT] = {"Ei", "Ew", "h", "D", "phi", "T0", "Tw", "Ti", "n", "E", "T", "Tg"};
+    return (f >= 0 && f < EBM_F_COUNT) ? names[f] : "?";
+}
+// a step (or a run of steps ending at global index `step`) has been launched
+void note_steps(ebm_ctx *h, long long nsteps, long long last_step, bool wrote_diag) {
+    h->epoch += nsteps;
+    h->state_step = last_step;
+    if (wrote_diag)
+        for (int f = 0; f < EBM_F_COUNT; ++f)
+            if (has_field(h, f) && is_diagnostic(h, f)) {
+                h->written_epoch[f] = h->epoch;
+                h->written_step[f] = last_step;
+            }
+}
+// EBM_OK if `f` may be read now, else EBM_ERR_STALE with the two steps in the message
+int check_current(const ebm_ctx *h, int f, const char *who) {
+    if (!is_diagnostic(h, f) || h->written_epoch[f] == h->epoch) return EBM_OK;
+    std::string msg = std::string(who) + ": field " + field_name(f) + " is stale — ";
+    if (h->written_epoch[f] < 0) msg += "it has never been written";
+    else msg += "last written by step " + std::to_string(h->written_step[f]);
+    msg += "; the state is at step " + std::to_string(h->state_step) +
+           (h->written_step[f] == h->state_step && h->written_epoch[f] >= 0 ? " with prognostic fields overwritten since" : "") +
+           " (take a step with write_diag / diag_last, or name the step: ebm_get_field_as_of)";
+    return fail(EBM_ERR_STALE, msg);
+}
 
 // Per-latitude constants.  Same expressions, in the same order, as the reference:
 // get_diffop (src/infrastructure.jl:480-492), the non-uniform cache (:509-518) and
@@ -266,7 +563,45 @@ int do_step(ebm_ctx *h, double ct, double ct_next, double f, int write_diag, lon
     h->n_steps += 1;
     h->n_launches += 1;
     h->clock = step + 1;
+    note_steps(h, 1, step, write_diag != 0);
+    // the 4-cells-per-thread MIZ step kernels leave the diagnostic fields pair-split (ensure_natural undoes it)
+    if (write_diag && h->model == EBM_MODEL_MIZ) h->diag_split = h->cfg.cells == 4;
     return EBM_OK;
+}
+
+// Readers of a diagnostic field get the natural layout: un-permute in place once after a step that stored them split.
+int ensure_natural(ebm_ctx *h) {
+    if (!h->diag_split) return EBM_OK;
+    hipError_t e = ebm::launch_unsplit_fields(h->field[EBM_F_Tw], h->fstride, 5, h->ncol, h->cfg, h->stream);
+    if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("unsplit_fields: ") + hipGetErrorString(e));
+    h->diag_split = false;
+    return EBM_OK;
+}
+bool is_split_field(const ebm_ctx *h, int f) {
+    return h->model == EBM_MODEL_MIZ && (f == EBM_F_Tw || f == EBM_F_Ti || f == EBM_F_n || f == EBM_F_E || f == EBM_F_T);
+}
+
+int get_copier(ebm_ctx *h) {
+    if (h->copier) return EBM_OK;
+    HostCopier *c = new HostCopier();
+    hipError_t e = c->init(h->device);
+    if (e != hipSuccess) {
+        c->shutdown();
+        delete c;
+        return fail(EBM_ERR_HIP, std::string("pinned staging ring: ") + hipGetErrorString(e));
+    }
+    h->copier = c;
+    return EBM_OK;
+}
+// (re)size one of the handle's kept device buffers
+hipError_t keep_buffer(double **buf, size_t *have, size_t want) {
+    if (*buf && *have >= want) return hipSuccess;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *have = 0;
+    hipError_t e = hipMalloc(buf, sizeof(double) * want);
+    if (e == hipSuccess) *have = want;
+    return e;
 }
 
 // quantity index (ebm::MizQuantity / ClassicQuantity) of a public field id, -1 if the step kernels
@@ -305,10 +640,37 @@ extern "C" {
 const char *ebm_last_error(void) { return g_err.c_str(); }
 const char *ebm_version(void) { return "ebm_hip 0.1 (gfx950)"; }
 
+int ebm_options_default(ebm_options *opt) {
+    if (!opt) return fail(EBM_ERR_ARG, "ebm_options_default: null argument");
+    opt->struct_bytes = (int)sizeof(ebm_options);
+    opt->cells_per_thread = 0;
+    opt->use_graph = -1;
+    opt->prefetch_cols = -1;
+    return EBM_OK;
+}
+
 int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const double *x,
                const double *params, double dt, int device) {
+    return ebm_create_ex(out, model, grid, nlat, ncol, x, params, dt, device, nullptr);
+}
+
+int ebm_create_ex(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const double *x,
+                  const double *params, double dt, int device, const ebm_options *user_opt) {
     if (!out || !x || !params) return fail(EBM_ERR_ARG, "ebm_create: null argument");
     *out = nullptr;
+    // options: the defaults, overwritten by as many fields as the caller's struct has (no environment is read)
+    ebm_options opt;
+    (void)ebm_options_default(&opt);
+    if (user_opt) {
+        if (user_opt->struct_bytes < (int)sizeof(int) || user_opt->struct_bytes > 4096)
+            return fail(EBM_ERR_ARG, "ebm_create_ex: options.struct_bytes must be sizeof(ebm_options)");
+        std::memcpy(&opt, user_opt, std::min((size_t)user_opt->struct_bytes, sizeof(opt)));
+        opt.struct_bytes = (int)sizeof(opt);
+    }
+    if (opt.cells_per_thread != 0 && opt.cells_per_thread != 2 && opt.cells_per_thread != 4)
+        return fail(EBM_ERR_ARG, "ebm_create_ex: cells_per_thread must be 0 (default), 2 or 4");
+    if (opt.use_graph < -1 || opt.use_graph > 1) return fail(EBM_ERR_ARG, "ebm_create_ex: use_graph must be -1, 0 or 1");
+    if (opt.prefetch_cols < -1) return fail(EBM_ERR_ARG, "ebm_create_ex: prefetch_cols must be -1 (default), 0 or a distance");
     if (model != EBM_MODEL_MIZ && model != EBM_MODEL_CLASSIC && model != EBM_MODEL_MIZ_IMEX)
         return fail(EBM_ERR_ARG, "ebm_create: unknown model");
     const bool imex = model == EBM_MODEL_MIZ_IMEX;        // the extension is the MIZ model with one more solve per step
@@ -318,12 +680,13 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
     if (!(dt > 0.0)) return fail(EBM_ERR_ARG, "ebm_create: dt must be positive");
     if (model == EBM_MODEL_MIZ && params[EBM_P_Tm] < 0.0 && params[EBM_P_m2] != std::floor(params[EBM_P_m2]))
         return fail(EBM_ERR_ARG, "ebm_create: Tm^m2 with Tm < 0 and non-integer m2 (DomainError in the reference, src/miz.jl:71)");
+    if (opt.cells_per_thread == 2 && (imex || nlat > ebm::kMaxLat2))
+        return fail(EBM_ERR_ARG, "ebm_create_ex: cells_per_thread = 2 needs nlat <= 1536 and is not built for the IMEX extension");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(EBM_ERR_NO_DEVICE, "ebm_create: no HIP device available (this library has no CPU path)");
     if (device < 0 || device >= ndev) return fail(EBM_ERR_ARG, "ebm_create: device index out of range");
-    const char *cv = std::getenv("EBM_CELLS_PER_THREAD");    // testing knob: 2 or 4 cells per thread
-    ebm::LaunchCfg cfg = ebm::choose_launch(nlat, ncol, imex ? 4 : (cv ? std::atoi(cv) : 0));   // the extension's kernels: 4 cells per thread
+    ebm::LaunchCfg cfg = ebm::choose_launch(nlat, opt.cells_per_thread);      // a function of nlat and the option only
     if (cfg.threads == 0)
         return fail(EBM_ERR_UNSUPPORTED, "ebm_create: nlat > 4096 is not supported (one workgroup owns a whole meridian)");
     HIPCHK(hipSetDevice(device));
@@ -333,24 +696,24 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
     ebm_ctx *h = new ebm_ctx();
     h->model = model; h->grid = grid; h->nlat = nlat; h->ncol = ncol; h->device = device;
     h->dt = dt; h->cfg = cfg; h->imex = imex;
-    {
-        h->num_cus = prop.multiProcessorCount;
-        // a step of fewer than ~256K cells is launch-bound: replay graphs in ebm_run (EBM_GRAPH=0/1 overrides)
-        const char *gv = std::getenv("EBM_GRAPH");
-        h->use_graph = gv ? std::atoi(gv) != 0 : ((long long)nlat * ncol <= 262144);
+    for (int f = 0; f < EBM_F_COUNT; ++f) {
+        h->written_epoch[f] = -1;
+        h->written_step[f] = -1;
     }
+    h->written_epoch[EBM_F_T0] = 0;                       // the warm start begins at zero, like the reference's (src/miz.jl:47)
+    h->num_cus = prop.multiProcessorCount;
+    // a step of fewer than ~256K cells is launch-bound: replay graphs in ebm_run
+    h->use_graph = opt.use_graph >= 0 ? opt.use_graph != 0 : ((long long)nlat * ncol <= 262144);
     {
         // One or two workgroups per CU (a long meridian fills the CU's LDS): little or nothing
         // overlaps the input loads of a workgroup, so each workgroup prefetches into L2 the inputs
         // of the one that follows it on its XCD (workgroups go round-robin over the XCDs and in
-        // order within one).  EBM_PREFETCH_COLS overrides (0 = off).
-        const char *pv = std::getenv("EBM_PREFETCH_COLS");
+        // order within one).
         int per_cu = (int)((160u * 1024u) / cfg.lds_bytes);                  // workgroups a CU holds: LDS ...
         if (per_cu > 2048 / cfg.threads) per_cu = 2048 / cfg.threads;         // ... and wave slots
         const int ahead = h->num_cus * per_cu;                                // the successor on the same XCD
         // measured: -3.5 % time at one workgroup per CU, -2.5 % at two, nothing beyond
-        h->prefetch = pv ? std::atoi(pv) : (per_cu <= 2 && ncol > ahead ? ahead : 0);
-        if (h->prefetch < 0) h->prefetch = 0;
+        h->prefetch = opt.prefetch_cols >= 0 ? opt.prefetch_cols : (per_cu <= 2 && ncol > ahead ? ahead : 0);
     }
     h->pitch = (long long)cfg.threads * cfg.cells;     // >= nlat; padding cells stay zero
     fill_params(h->p, params, dt);
@@ -390,6 +753,12 @@ int ebm_destroy(ebm_handle_t h) {
     if (!h) return EBM_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->copier) {
+        h->copier->shutdown();
+        delete h->copier;
+    }
+    for (double *b : {h->scratch, h->ig_sums, h->ig_mean, h->ig_snap, h->ig_stage, h->ig_hm})
+        if (b) (void)hipFree(b);
     if (h->geom) (void)hipFree(h->geom);
     if (h->state) (void)hipFree(h->state);
     if (h->p_dev) (void)hipFree(h->p_dev);
@@ -412,35 +781,86 @@ int ebm_set_field(ebm_handle_t h, int field, const double *host) {
     if (!h || !host) return fail(EBM_ERR_ARG, "ebm_set_field: null argument");
     if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_set_field: field not part of this model");
     HIPCHK(hipSetDevice(h->device));
+    int rc = get_copier(h);
+    if (rc) return rc;
+    if (is_split_field(h, field)) {
+        rc = ensure_natural(h);                   // the other diagnostic fields keep their values, in the natural layout
+        if (rc) return rc;
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
-    HIPCHK(hipMemcpy2D(h->field[field], sizeof(double) * h->pitch, host, sizeof(double) * h->nlat,
-                       sizeof(double) * h->nlat, h->ncol, hipMemcpyHostToDevice));
+    HIPCHK(h->copier->wait_all());
+    HIPCHK(h->copier->upload(h->field[field], (size_t)h->pitch, host, (size_t)h->nlat, (size_t)h->ncol));
     if (field == EBM_F_T0 && h->model == EBM_MODEL_MIZ) {
         // the stepping kernels carry the warm start as its active set: rebuild it from the new T0
         hipError_t e = ebm::launch_mask_from_t0(base_args(h), h->ncol, h->cfg, h->stream);
         if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("mask_from_t0: ") + hipGetErrorString(e));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
+    if (is_diagnostic(h, field)) {                // the caller's statement of what the field holds: current as of now
+        h->written_epoch[field] = h->epoch;
+        h->written_step[field] = h->state_step;
+    } else {
+        h->epoch += 1;                            // the prognostic state changed: every diagnostic field is older than it now
+    }
+    return EBM_OK;
+}
+
+// device -> host through the pinned ring (synchronous)
+static int download_field(ebm_handle_t h, int field, double *host, const char *who) {
+    int rc = get_copier(h);
+    if (rc) return rc;
+    if (is_split_field(h, field)) {
+        rc = ensure_natural(h);
+        if (rc) return rc;
+    }
+    HostCopier *c = h->copier;
+    HIPCHK(c->wait_all());
+    HIPCHK(c->order_after(h->stream));
+    CopyJob j;
+    j.src = h->field[field]; j.src_pitch = (size_t)h->pitch; j.row_elems = (size_t)h->nlat; j.nrows = (size_t)h->ncol; j.dst = host;
+    hipError_t e = c->run(j);
+    if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
     return EBM_OK;
 }
 
 int ebm_get_field(ebm_handle_t h, int field, double *host) {
     if (!h || !host) return fail(EBM_ERR_ARG, "ebm_get_field: null argument");
     if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_get_field: field not part of this model");
+    int rc = check_current(h, field, "ebm_get_field");
+    if (rc) return rc;
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->pitch == h->nlat)       // no padding: one contiguous copy
-        HIPCHK(hipMemcpy(host, h->field[field], sizeof(double) * (size_t)h->nlat * h->ncol, hipMemcpyDeviceToHost));
-    else
-        HIPCHK(hipMemcpy2D(host, sizeof(double) * h->nlat, h->field[field], sizeof(double) * h->pitch,
-                           sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToHost));
+    return download_field(h, field, host, "ebm_get_field");
+}
+
+int ebm_get_field_as_of(ebm_handle_t h, int field, long long step, double *host) {
+    if (!h || !host) return fail(EBM_ERR_ARG, "ebm_get_field_as_of: null argument");
+    if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_get_field_as_of: field not part of this model");
+    const long long have = is_diagnostic(h, field) ? (h->written_epoch[field] >= 0 ? h->written_step[field] : -2) : h->state_step;
+    if (have != step)
+        return fail(EBM_ERR_STALE, std::string("ebm_get_field_as_of: field ") + field_name(field) + " is not as of step " +
+                                       std::to_string(step) + (have == -2 ? " (it has never been written)"
+                                                                          : " (it was last written by step " + std::to_string(have) + ")"));
+    HIPCHK(hipSetDevice(h->device));
+    return download_field(h, field, host, "ebm_get_field_as_of");
+}
+
+int ebm_field_step(ebm_handle_t h, int field, long long *written_step, long long *state_step, int *current) {
+    if (!h) return fail(EBM_ERR_ARG, "ebm_field_step: null handle");
+    if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_field_step: field not part of this model");
+    const bool diag = is_diagnostic(h, field);
+    if (written_step) *written_step = diag ? (h->written_epoch[field] >= 0 ? h->written_step[field] : -1) : h->state_step;
+    if (state_step) *state_step = h->state_step;
+    if (current) *current = (!diag || h->written_epoch[field] == h->epoch) ? 1 : 0;
     return EBM_OK;
 }
 
 int ebm_hemispheric_mean(ebm_handle_t h, int field, double *out) {
     if (!h || !out) return fail(EBM_ERR_ARG, "ebm_hemispheric_mean: null argument");
     if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_hemispheric_mean: field not part of this model");
+    int rc = check_current(h, field, "ebm_hemispheric_mean");
+    if (rc) return rc;
     HIPCHK(hipSetDevice(h->device));
+    if (is_split_field(h, field) && (rc = ensure_natural(h))) return rc;
     hipError_t e = ebm::launch_hemispheric_mean(h->field[field], h->geom + (size_t)ebm::G_X * h->gstride, (int)h->pitch,
                                                 h->nlat, h->ncol, h->hm_dev, h->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, h->hm_dev, sizeof(double) * (size_t)h->ncol, hipMemcpyDeviceToHost, h->stream);
@@ -452,7 +872,10 @@ int ebm_hemispheric_mean(ebm_handle_t h, int field, double *out) {
 int ebm_hemispheric_mean_device(ebm_handle_t h, int field, double *dev_out) {
     if (!h || !dev_out) return fail(EBM_ERR_ARG, "ebm_hemispheric_mean_device: null argument");
     if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_hemispheric_mean_device: field not part of this model");
+    int rc = check_current(h, field, "ebm_hemispheric_mean_device");
+    if (rc) return rc;
     HIPCHK(hipSetDevice(h->device));
+    if (is_split_field(h, field) && (rc = ensure_natural(h))) return rc;
     hipError_t e = ebm::launch_hemispheric_mean(h->field[field], h->geom + (size_t)ebm::G_X * h->gstride, (int)h->pitch,
                                                 h->nlat, h->ncol, dev_out, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -463,7 +886,10 @@ int ebm_hemispheric_mean_device(ebm_handle_t h, int field, double *dev_out) {
 int ebm_get_field_device(ebm_handle_t h, int field, double *dev_out) {
     if (!h || !dev_out) return fail(EBM_ERR_ARG, "ebm_get_field_device: null argument");
     if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_get_field_device: field not part of this model");
+    int rc = check_current(h, field, "ebm_get_field_device");
+    if (rc) return rc;
     HIPCHK(hipSetDevice(h->device));
+    if (is_split_field(h, field) && (rc = ensure_natural(h))) return rc;
     HIPCHK(hipMemcpy2DAsync(dev_out, sizeof(double) * h->nlat, h->field[field], sizeof(double) * h->pitch,
                             sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -476,14 +902,16 @@ int ebm_diffusion(ebm_handle_t h, const double *temp, const double *base, double
         return fail(EBM_ERR_ARG, "ebm_diffusion: needs a MIZ handle (the classic model carries get_diffop unscaled inside kappa, src/classic.jl:21)");
     HIPCHK(hipSetDevice(h->device));
     const size_t npitch = (size_t)h->ncol * h->pitch;
-    double *buf = nullptr;                               // temp | base | out, [ncol][pitch] each
-    HIPCHK(hipMalloc(&buf, sizeof(double) * npitch * 3));
-    hipError_t e = hipMemsetAsync(buf, 0, sizeof(double) * npitch * 3, h->stream);
+    if (!h->scratch) {                                   // temp | base | out, [ncol][pitch] each: kept until ebm_destroy
+        HIPCHK(hipMalloc(&h->scratch, sizeof(double) * npitch * 3));
+        HIPCHK(hipMemsetAsync(h->scratch, 0, sizeof(double) * npitch * 3, h->stream));       // padding cells stay zero
+    }
+    double *buf = h->scratch;
     auto up = [&](double *dst, const double *src) {
         return hipMemcpy2DAsync(dst, sizeof(double) * h->pitch, src, sizeof(double) * h->nlat, sizeof(double) * h->nlat,
                                 h->ncol, hipMemcpyHostToDevice, h->stream);
     };
-    if (e == hipSuccess) e = up(buf, temp);
+    hipError_t e = up(buf, temp);
     if (e == hipSuccess && base) e = up(buf + npitch, base);
     if (e == hipSuccess)
         e = ebm::launch_diffusion(buf, base ? buf + npitch : nullptr, buf + 2 * npitch, h->geom, h->gstride, h->p_dev,
@@ -492,7 +920,6 @@ int ebm_diffusion(ebm_handle_t h, const double *temp, const double *base, double
         e = hipMemcpy2DAsync(out, sizeof(double) * h->nlat, buf + 2 * npitch, sizeof(double) * h->pitch,
                              sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(buf);
     if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("ebm_diffusion: ") + hipGetErrorString(e));
     return EBM_OK;
 }
@@ -500,6 +927,13 @@ int ebm_diffusion(ebm_handle_t h, const double *temp, const double *base, double
 int ebm_field_device_ptr(ebm_handle_t h, int field, double **dptr, long long *pitch) {
     if (!h || !dptr) return fail(EBM_ERR_ARG, "ebm_field_device_ptr: null argument");
     if (!has_field(h, field)) return fail(EBM_ERR_ARG, "ebm_field_device_ptr: field not part of this model");
+    int rc = check_current(h, field, "ebm_field_device_ptr");
+    if (rc) return rc;
+    if (is_split_field(h, field)) {                      // the view is of the natural layout as of this call
+        HIPCHK(hipSetDevice(h->device));
+        if ((rc = ensure_natural(h))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     *dptr = h->field[field];
     if (pitch) *pitch = h->pitch;
     return EBM_OK;
@@ -588,6 +1022,7 @@ int ebm_run(ebm_handle_t h, long long first_step, int nsteps, const double *f_st
             h->n_steps += kGraphSteps;
             h->n_launches += kGraphSteps;
             h->clock = first_step + s + kGraphSteps;
+            note_steps(h, kGraphSteps, first_step + s + kGraphSteps - 1, false);
         }
     }
     for (; s < nsteps; ++s) {
@@ -634,6 +1069,8 @@ int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double
             hipError_t e = launch_step(h, a, ebm::OUT_LOOP);
             if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
             h->n_launches += 1;
+            note_steps(h, a.nfused, first_step + s0 + i + a.nfused - 1, a.write_diag != 0);
+            if (a.write_diag && h->model == EBM_MODEL_MIZ) h->diag_split = false;      // the fused kernel stores them in the natural layout
         }
         h->n_steps += n;
         h->clock = first_step + s0 + n;
@@ -643,6 +1080,12 @@ int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double
 
 // integrate + savesol! (ebm_integrate) with, optionally, the per-column hemispheric means of the seasonal
 // outputs reduced on the device (ebm_integrate_hemispheric): hm_* are [nvars][dur][ncol] host arrays.
+//
+// Host output never stalls the stepping: what has to leave the device is first copied device -> device into a
+// buffer of its own on the compute stream (seasonal snapshots; the annual means come out of ONE finish-mean
+// launch; raw snapshots are written by the step kernel into one half of a two-part staging buffer), then the
+// handle's copier moves it to the caller's arrays — DMA into the pinned ring on its own stream, host threads
+// from there — while the following steps run.  A buffer is reused only after the job that reads it has finished.
 static int integrate_impl(ebm_handle_t h, int nt, int dur, const double *f_steps, int lastonly,
                           int winter_inx, int summer_inx, int nvars, const int *fields, double *raw,
                           double *winter, double *summer, double *avg, double *hm_winter, double *hm_summer,
@@ -660,36 +1103,46 @@ static int integrate_impl(ebm_handle_t h, int nt, int dur, const double *f_steps
         save.var_of[q] = (signed char)v;
     }
     HIPCHK(hipSetDevice(h->device));
+    int rc = get_copier(h);
+    if (rc) return rc;
+    HostCopier *cp = h->copier;
+    HIPCHK(cp->wait_all());
     const size_t ncell = (size_t)h->ncol * h->nlat;          // packed cells per snapshot (host side)
     const size_t npitch = (size_t)h->ncol * h->pitch;        // device elements per field
     const long long total = (long long)nt * dur;
     const long long nraw = lastonly ? nt : total;
-    // Device buffers: raw snapshots are staged as [var][chunk][ncol][pitch] and flushed to the host
-    // when the chunk is full; the annual-mean sums are [var][ncol*pitch] (pair-split layout).
-    long long chunk = 0;
-    double *stage = nullptr, *sums = nullptr, *mean = nullptr, *hm = nullptr;
-    auto cleanup = [&]() {
-        if (stage) (void)hipFree(stage);
-        if (sums) (void)hipFree(sums);
-        if (mean) (void)hipFree(mean);
-        if (hm) (void)hipFree(hm);
-    };
+    const bool want_hm = (hm_winter || hm_summer || hm_avg) && nvars > 0;
+    const bool want_sums = (avg || hm_avg) && nvars > 0;
+    const bool want_snap = (winter || summer) && nvars > 0;
+    // Any failure: let the copier finish what it was given (it reads this call's device buffers) before returning.
 #define EBM_TRY(expr)                                                                     \
     do {                                                                                  \
         hipError_t e_ = (expr);                                                           \
         if (e_ != hipSuccess) {                                                           \
-            cleanup();                                                                    \
+            (void)cp->wait_all();                                                         \
             return fail(EBM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
         }                                                                                 \
     } while (0)
+    // Device buffers (kept in the handle between calls): raw snapshots are staged as two halves of
+    // [var][chunk][ncol][pitch]; the annual-mean sums are [var][ncol*pitch] (pair-split layout), the means and the
+    // seasonal snapshots [var][ncol*pitch] in the natural layout.
+    long long chunk = 0;
     if (raw && nvars > 0) {
-        chunk = (long long)((256ull << 20) / (sizeof(double) * npitch * (size_t)nvars));
+        chunk = (long long)((128ull << 20) / (sizeof(double) * npitch * (size_t)nvars));
         if (chunk < 1) chunk = 1;
         if (chunk > nraw) chunk = nraw;
-        EBM_TRY(hipMalloc(&stage, sizeof(double) * npitch * (size_t)nvars * (size_t)chunk));
+        EBM_TRY(keep_buffer(&h->ig_stage, &h->ig_stage_n, 2 * npitch * (size_t)nvars * (size_t)chunk));
     }
-    if ((hm_winter || hm_summer || hm_avg) && nvars > 0)
-        EBM_TRY(hipMalloc(&hm, sizeof(double) * (size_t)h->ncol * (size_t)nvars));
+    if (want_hm) EBM_TRY(keep_buffer(&h->ig_hm, &h->ig_hm_n, (size_t)h->ncol * (size_t)nvars));
+    if (want_sums) {
+        EBM_TRY(keep_buffer(&h->ig_sums, &h->ig_sums_n, npitch * (size_t)nvars));
+        EBM_TRY(hipMemsetAsync(h->ig_sums, 0, sizeof(double) * npitch * (size_t)nvars, h->stream));
+        EBM_TRY(keep_buffer(&h->ig_mean, &h->ig_mean_n, npitch * (size_t)nvars));
+    }
+    if (want_snap) EBM_TRY(keep_buffer(&h->ig_snap, &h->ig_snap_n, npitch * (size_t)nvars));
+    double *const sums = want_sums ? h->ig_sums : nullptr, *const mean = h->ig_mean, *const snap = h->ig_snap;
+    double *const hm = h->ig_hm;
+    double *const stage = (raw && nvars > 0) ? h->ig_stage : nullptr;
     // hemispheric_mean (src/utilities.jl:397-403) of every saved variable of a padded device field set,
     // reduced on the device, [nvars][ncol] -> out[v][year][col]
     auto means_to_host = [&](double *out, long long year, auto field_of) -> hipError_t {
@@ -704,32 +1157,46 @@ static int integrate_impl(ebm_handle_t h, int nt, int dur, const double *f_steps
                           sizeof(double) * (size_t)h->ncol, hipMemcpyDeviceToHost);
         return e;
     };
-    if ((avg || hm_avg) && nvars > 0) {
-        EBM_TRY(hipMalloc(&sums, sizeof(double) * npitch * (size_t)nvars));
-        EBM_TRY(hipMemsetAsync(sums, 0, sizeof(double) * npitch * (size_t)nvars, h->stream));
-        EBM_TRY(hipMalloc(&mean, sizeof(double) * npitch));
-    }
     save.sums = sums;
     save.sum_stride = (long long)npitch;
     save.stage_var_stride = chunk * (long long)npitch;
-    auto snapshot_to_host = [&](double *dst, const double *src_dev) -> hipError_t {
-        return hipMemcpy2DAsync(dst, sizeof(double) * h->nlat, src_dev, sizeof(double) * h->pitch,
-                                sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToHost, h->stream);
+    // one asynchronous job per saved variable: [ncol][pitch] on the device -> packed [ncol][nlat] at dst
+    auto fields_to_host = [&](double *dst_base, long long year, const double *dev_base) -> hipError_t {
+        hipError_t e = cp->order_after(h->stream);
+        for (int v = 0; v < nvars && e == hipSuccess; ++v) {
+            CopyJob j;
+            j.src = dev_base + (size_t)v * npitch; j.src_pitch = (size_t)h->pitch; j.row_elems = (size_t)h->nlat;
+            j.nrows = (size_t)h->ncol; j.dst = dst_base + ((size_t)v * dur + (size_t)(year - 1)) * ncell;
+            cp->submit(j);
+        }
+        return e;
     };
-    long long staged = 0, raw_base = 0;   // snapshots in the staging buffer; raw index of its first
+    // seasonal snapshot: the state fields of this step, device -> device, then out
+    auto season_to_host = [&](double *dst_base, long long year) -> hipError_t {
+        hipError_t e = cp->wait_all();                                       // the previous snapshot has left `snap`
+        for (int v = 0; v < nvars && e == hipSuccess; ++v)
+            e = hipMemcpyAsync(snap + (size_t)v * npitch, h->field[fields[v]], sizeof(double) * npitch, hipMemcpyDeviceToDevice, h->stream);
+        if (e == hipSuccess) e = fields_to_host(dst_base, year, snap);
+        return e;
+    };
+    long long staged = 0, raw_base = 0;   // snapshots in the current half of the staging buffer; raw index of its first
+    int half = 0;
+    const long long clock0 = h->clock;    // model time continues from the handle's step clock (0 after ebm_create)
     auto flush = [&]() -> hipError_t {
         if (!staged) return hipSuccess;
-        for (int v = 0; v < nvars; ++v) {
-            // `staged` snapshots of ncol rows each: (staged * ncol) rows of nlat doubles, pitch apart
-            hipError_t e = hipMemcpy2DAsync(raw + ((size_t)v * nraw + raw_base) * ncell, sizeof(double) * h->nlat,
-                                            stage + (size_t)v * chunk * npitch, sizeof(double) * h->pitch,
-                                            sizeof(double) * h->nlat, (size_t)staged * h->ncol,
-                                            hipMemcpyDeviceToHost, h->stream);
-            if (e != hipSuccess) return e;
+        // the half just filled goes out while the steps fill the other one — whose previous contents must have left
+        hipError_t e = cp->wait_all();
+        if (e == hipSuccess) e = cp->order_after(h->stream);
+        for (int v = 0; v < nvars && e == hipSuccess; ++v) {
+            CopyJob j;      // `staged` snapshots of ncol rows each: (staged * ncol) rows of nlat doubles, pitch apart
+            j.src = stage + (size_t)half * (size_t)nvars * chunk * npitch + (size_t)v * chunk * npitch;
+            j.src_pitch = (size_t)h->pitch; j.row_elems = (size_t)h->nlat; j.nrows = (size_t)staged * h->ncol;
+            j.dst = raw + ((size_t)v * nraw + raw_base) * ncell;
+            cp->submit(j);
         }
-        hipError_t e = hipStreamSynchronize(h->stream);
         raw_base += staged;
         staged = 0;
+        half ^= 1;
         return e;
     };
     for (long long tinx = 1; tinx <= total; ++tinx) {              // 1-based, as the reference
@@ -742,44 +1209,34 @@ static int integrate_impl(ebm_handle_t h, int nt, int dur, const double *f_steps
         const bool want_raw = stage && (!lastonly || tinx > total - nt);
         const bool want_season = (ti == winter_inx && (winter || hm_winter)) || (ti == summer_inx && (summer || hm_summer));
         const int diag = (want_season || tinx == total) ? 1 : 0;
-        save.stage = want_raw ? stage : nullptr;
+        save.stage = want_raw ? stage + (size_t)half * (size_t)nvars * chunk * npitch : nullptr;
         save.stage_offset = staged * (long long)npitch;
-        int rc = do_step(h, h->ttab[ti - 1], h->ttab[ti % nt], f, diag, tinx - 1, (sums || want_raw) ? &save : nullptr);
-        if (rc) { cleanup(); return rc; }
+        rc = do_step(h, h->ttab[ti - 1], h->ttab[ti % nt], f, diag, clock0 + tinx - 1, (sums || want_raw) ? &save : nullptr);
+        if (rc) { (void)cp->wait_all(); return rc; }
         if (want_raw && ++staged == chunk) EBM_TRY(flush());
         auto state_field = [&](int v) { return (const double *)h->field[fields[v]]; };
+        if (want_season && (rc = ensure_natural(h))) { (void)cp->wait_all(); return rc; }
         if (ti == winter_inx) {
-            if (winter)
-                for (int v = 0; v < nvars; ++v)
-                    EBM_TRY(snapshot_to_host(winter + ((size_t)v * dur + (year - 1)) * ncell, h->field[fields[v]]));
+            if (winter) EBM_TRY(season_to_host(winter, year));
             if (hm_winter) EBM_TRY(means_to_host(hm_winter, year, state_field));
         } else if (ti == summer_inx) {
-            if (summer)
-                for (int v = 0; v < nvars; ++v)
-                    EBM_TRY(snapshot_to_host(summer + ((size_t)v * dur + (year - 1)) * ncell, h->field[fields[v]]));
+            if (summer) EBM_TRY(season_to_host(summer, year));
             if (hm_summer) EBM_TRY(means_to_host(hm_summer, year, state_field));
         } else if (ti == nt) {
-            if (sums)
-                for (int v = 0; v < nvars; ++v) {
-                    EBM_TRY(ebm::launch_finish_mean(mean, sums + (size_t)v * npitch, (double)nt, h->ncol, h->cfg, h->stream));
-                    if (avg) EBM_TRY(snapshot_to_host(avg + ((size_t)v * dur + (year - 1)) * ncell, mean));
-                    if (hm_avg) {
-                        EBM_TRY(ebm::launch_hemispheric_mean(mean, h->geom + (size_t)ebm::G_X * h->gstride, (int)h->pitch,
-                                                             h->nlat, h->ncol, hm + (size_t)v * h->ncol, h->stream));
-                        EBM_TRY(hipStreamSynchronize(h->stream));
-                        EBM_TRY(hipMemcpy(hm_avg + ((size_t)v * dur + (size_t)(year - 1)) * h->ncol, hm + (size_t)v * h->ncol,
-                                          sizeof(double) * (size_t)h->ncol, hipMemcpyDeviceToHost));
-                    }
-                    EBM_TRY(hipStreamSynchronize(h->stream));
-                }
+            if (sums) {
+                EBM_TRY(cp->wait_all());                                     // last year's means have left `mean`
+                EBM_TRY(ebm::launch_finish_mean(mean, sums, (double)nt, h->ncol, nvars, (long long)npitch, h->cfg, h->stream));
+                if (avg) EBM_TRY(fields_to_host(avg, year, mean));
+                if (hm_avg) EBM_TRY(means_to_host(hm_avg, year, [&](int v) { return (const double *)(mean + (size_t)v * npitch); }));
+            }
         }
         if (sums && ti == nt && !(ti != winter_inx && ti != summer_inx))   // year ended on a seasonal index:
             EBM_TRY(hipMemsetAsync(sums, 0, sizeof(double) * npitch * (size_t)nvars, h->stream));  // no mean is taken, restart sums
     }
     EBM_TRY(flush());
     EBM_TRY(hipStreamSynchronize(h->stream));
+    EBM_TRY(cp->wait_all());
 #undef EBM_TRY
-    cleanup();
     return EBM_OK;
 }
 

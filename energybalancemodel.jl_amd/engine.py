@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 
 import numpy as np
 
@@ -40,9 +41,20 @@ def param_vector(par, defaults) -> np.ndarray:
     return np.array([get(k, defaults[k]) for k in PARAM_ORDER], dtype=np.float64)
 
 
+def _env_int(name):
+    v = os.environ.get(name)
+    return None if v in (None, "") else int(v)
+
+
 class Engine:
+    """``cells_per_thread`` (2 or 4; default 4), ``use_graph`` (True / False; default: by size) and
+    ``prefetch_cols`` are the launch options of ``ebm_create_ex`` (include/ebm_hip.h: struct ebm_options).
+    The LIBRARY reads no environment variable; this mirror maps EBM_CELLS_PER_THREAD, EBM_GRAPH and
+    EBM_PREFETCH_COLS to those options when the corresponding argument is left at None — the knobs of the
+    test suite and of the A/B timing scripts under tests/tools/."""
+
     def __init__(self, model: str, grid_kind: str, x, params25, dt: float, ncol: int = 1,
-                 device: int = 0):
+                 device: int = 0, *, cells_per_thread=None, use_graph=None, prefetch_cols=None):
         if model not in MODEL:
             raise ValueError(f"unknown model {model!r}: expected 'MIZ', 'Classic' or the extension 'MIZ_IMEX'")
         self.lib = _lib.load()
@@ -50,10 +62,26 @@ class Engine:
         self.x = as_f64(x)
         self.nlat, self.ncol, self.dt = int(self.x.shape[0]), int(ncol), float(dt)
         self.params = as_f64(params25, (len(PARAM_ORDER),))
+        opt = _lib.Options()
+        check(self.lib.ebm_options_default(C.byref(opt)), "ebm_options_default")
+        if cells_per_thread is None:
+            cells_per_thread = _env_int("EBM_CELLS_PER_THREAD")
+            if cells_per_thread == 2 and (self.nlat > 1536 or model == "MIZ_IMEX"):
+                cells_per_thread = None              # the knob asks for 2 "where it exists"
+        if use_graph is None and _env_int("EBM_GRAPH") is not None:
+            use_graph = bool(_env_int("EBM_GRAPH"))
+        if prefetch_cols is None:
+            prefetch_cols = _env_int("EBM_PREFETCH_COLS")
+        if cells_per_thread is not None:
+            opt.cells_per_thread = int(cells_per_thread)
+        if use_graph is not None:
+            opt.use_graph = int(bool(use_graph))
+        if prefetch_cols is not None:
+            opt.prefetch_cols = max(0, int(prefetch_cols))
         h = C.c_void_p()
         gk = GRID["identity"] if grid_kind == "identity" else GRID["nonuniform"]
-        check(self.lib.ebm_create(C.byref(h), MODEL[model], gk, self.nlat, self.ncol,
-                                  dptr(self.x), dptr(self.params), self.dt, int(device)),
+        check(self.lib.ebm_create_ex(C.byref(h), MODEL[model], gk, self.nlat, self.ncol,
+                                     dptr(self.x), dptr(self.params), self.dt, int(device), C.byref(opt)),
               "ebm_create")
         self._h = h
         self.nt = None
@@ -93,6 +121,20 @@ class Engine:
         out = np.empty((self.ncol, self.nlat))
         check(self.lib.ebm_get_field(self._h, FIELD[name], dptr(out)), f"ebm_get_field({name})")
         return out
+
+    def get_field_as_of(self, name: str, step: int) -> np.ndarray:
+        """The field as written by global step ``step`` (0-based), however far the state has moved on since;
+        StaleFieldError if another step wrote it last (ebm_get_field_as_of)."""
+        out = np.empty((self.ncol, self.nlat))
+        check(self.lib.ebm_get_field_as_of(self._h, FIELD[name], int(step), dptr(out)), f"ebm_get_field_as_of({name})")
+        return out
+
+    def field_step(self, name: str) -> dict:
+        """dict(written_step, state_step, current): which step last wrote the field, where the state is, and
+        whether the field may be read now (ebm_field_step)."""
+        w, s_, c = C.c_longlong(), C.c_longlong(), C.c_int()
+        check(self.lib.ebm_field_step(self._h, FIELD[name], C.byref(w), C.byref(s_), C.byref(c)), "ebm_field_step")
+        return dict(written_step=w.value, state_step=s_.value, current=bool(c.value))
 
     def set_state(self, state: dict):
         for k, v in state.items():

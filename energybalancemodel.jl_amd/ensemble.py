@@ -38,9 +38,12 @@ class EnsembleRun:
     ``init`` maps prognostic names to [ncol, nlat] arrays (or [nlat], broadcast to all
     columns); ``fcol`` is the per-column forcing offset; ``forcings`` a sequence of one Forcing
     per column, evaluated on the device at every step (hysteresis ensembles: every member its own
-    ramp)."""
+    ramp).
 
-    def __init__(self, model, st, par, init, fcol=None, device=0, forcings=None):
+    A column's results do not depend on how many columns share its handle or on how the ensemble is sharded
+    over GPUs: the launch geometry is a function of the latitude count and ``cells_per_thread`` only."""
+
+    def __init__(self, model, st, par, init, fcol=None, device=0, forcings=None, cells_per_thread=None):
         first = np.asarray(next(iter(init.values())))
         self.ncol = 1 if first.ndim == 1 else first.shape[0]
         if fcol is not None:
@@ -49,8 +52,10 @@ class EnsembleRun:
             self.ncol = len(forcings)
         self.st = st
         self.device = int(device)
+        # cells_per_thread: launch option of ebm_create_ex (None = the library's default of 4).  Every rank of a
+        # sharded run must pass the same value: the rounding of the solves depends on it and on nothing else
         self.engine = Engine(model, st.grid_kind, st.x, param_vector(par, default_parval), st.dt,
-                             self.ncol, device)
+                             self.ncol, device, cells_per_thread=cells_per_thread)
         for k, v in init.items():
             a = np.asarray(v, dtype=np.float64)
             if a.ndim == 1:
@@ -80,13 +85,18 @@ class EnsembleRun:
         device (ebm_integrate_hemispheric): dict(winter, summer, avg), each [len(names), years, ncol].
         This is the data behind the reference's hysteresis plot (src/plot.jl:173-225: hemispheric_mean
         of seasonal.avg.T[year] against 2*pi*hemispheric_mean of seasonal.{avg,winter,summer}.phi[year])
-        for every member, at O(members x years) bytes of I/O.  Model time (and with it the per-column
-        Forcing schedules) starts at 0 at the call, as in the reference's ``integrate``."""
+        for every member, at O(members x years) bytes of I/O.  Model time — the scalar ``forcing`` and the
+        per-column Forcing schedules — continues from the steps this run has already taken, so a ramp integrated
+        in several calls (chunks of years) equals the same ramp integrated in one; the calls must start at a
+        year boundary, as the reference's ``integrate`` does."""
         st = self.st
+        if self.step_index % st.nt:
+            raise ValueError(f"seasonal_means starts a year: {self.step_index} steps taken so far is not a multiple of nt = {st.nt}")
         f = None
         if forcing is not None:
-            T = (np.arange(st.nt * years) + 0.5) * st.dt
+            T = (np.arange(self.step_index, self.step_index + st.nt * years) + 0.5) * st.dt
             f = np.array([forcing(float(t)) for t in T])
+        self.engine.set_step_clock(self.step_index)
         out = self.engine.integrate_hemispheric(st.nt, years, f, st.winter.inx, st.summer.inx, tuple(names))
         self.step_index += st.nt * years
         return out

@@ -14,6 +14,7 @@ reference's ``Solutions``.  Julia symbols become strings: ``:MIZ`` -> "MIZ", ``:
 from __future__ import annotations
 
 import math
+import os
 import warnings
 from fractions import Fraction
 
@@ -203,7 +204,13 @@ def _check_model(model):
 
 
 def _new_engine(model, st, par, ncol=1, device=0) -> Engine:
-    return Engine(model, st.grid_kind, st.x, param_vector(par, default_parval), st.dt, ncol, device)
+    """The reference's own shapes are ONE meridian: such a run is latency-bound on a handful of waves, and two
+    latitudes per thread (ebm_options.cells_per_thread = 2, meridians of up to 1536 cells) put twice as many of
+    them to work.  The choice is made HERE, explicitly, and never by the library from the number of columns: the
+    partition of the tridiagonal solves — hence their rounding — depends on it (include/ebm_hip.h)."""
+    cells = 2 if (ncol == 1 and st.nx <= 1536 and model != "MIZ_IMEX" and os.environ.get("EBM_CELLS_PER_THREAD") is None) else None
+    return Engine(model, st.grid_kind, st.x, param_vector(par, default_parval), st.dt, ncol, device,
+                  cells_per_thread=cells)
 
 
 def classic_time_index(t: float, dt: float, nt: int) -> int:

@@ -42,7 +42,8 @@ enum ebm_status {
     EBM_ERR_ARG = -1,      /* bad argument */
     EBM_ERR_HIP = -2,      /* HIP runtime error */
     EBM_ERR_UNSUPPORTED = -3,
-    EBM_ERR_NO_DEVICE = -4 /* no usable GPU: the library never falls back to the CPU */
+    EBM_ERR_NO_DEVICE = -4, /* no usable GPU: the library never falls back to the CPU */
+    EBM_ERR_STALE = -5      /* the requested field is older than the state (see "Validity" below) */
 };
 
 /* model tag == the Val{...} the reference dispatches step! on (src/infrastructure.jl:594).
@@ -98,15 +99,62 @@ enum ebm_field {
  * warm start does).  Fails with EBM_ERR_NO_DEVICE when no GPU is present. */
 int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const double *x,
                const double *params, double dt, int device);
+
+/* Launch options.  The library reads NO environment variable: whatever changes how a handle runs is passed
+ * here.  Zero-initialise (or call ebm_options_default) and set struct_bytes = sizeof(ebm_options); fields the
+ * caller's struct does not have keep their defaults, so the struct can grow.
+ *
+ * cells_per_thread: latitudes per thread of the one workgroup that owns a meridian — 4 (default: 32
+ *   contiguous bytes per lane and field, the throughput geometry) or 2 (nlat <= 1536: twice as many waves
+ *   per meridian, for latency-bound runs of a FEW short meridians, e.g. one 180-band column).  The
+ *   tridiagonal partition, hence the ROUNDING of the T0 / Tg solves, depends on this number and on nothing
+ *   else a caller controls: the geometry is a function of (nlat, cells_per_thread) only — never of ncol — so
+ *   a member gives the same bits alone, inside a large ensemble, and under any sharding over GPUs, as long as
+ *   every rank passes the same options.
+ * use_graph: replay hipGraphs of 64 captured step launches in ebm_run (-1 = by size: on for steps of at most
+ *   262,144 cells, which are launch-bound; 0 = off; 1 = on).  Bit-identical either way.
+ * prefetch_cols: L2-prefetch distance of the MIZ step kernel in columns (-1 = the successor workgroup on the
+ *   same XCD when at most two workgroups fit a CU, else off; 0 = off).  Performance only. */
+typedef struct ebm_options {
+    int struct_bytes;
+    int cells_per_thread;
+    int use_graph;
+    int prefetch_cols;
+} ebm_options;
+int ebm_options_default(ebm_options *opt);
+/* ebm_create with explicit options (opt == NULL: the defaults, i.e. exactly ebm_create). */
+int ebm_create_ex(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const double *x,
+                  const double *params, double dt, int device, const ebm_options *opt);
 int ebm_destroy(ebm_handle_t h);
 const char *ebm_last_error(void);
 const char *ebm_version(void);
 
 /* ---- state --------------------------------------------------------------------------- */
 
-/* Copy a whole field host<->device ([ncol][nlat] doubles, synchronous). */
+/* Copy a whole field host<->device ([ncol][nlat] doubles, synchronous).  The copies run through a pinned
+ * staging ring owned by the handle (device -> pinned by DMA while the previous piece is copied on to the
+ * caller's pageable buffer by a few host threads).
+ *
+ * Validity.  The prognostic fields are always current.  The diagnostic fields (MIZ: Tw, Ti, n, E, T; classic:
+ * T, h) and the fp64 warm start EBM_F_T0 are written only by steps that were asked to (ebm_step with
+ * write_diag, the last step of ebm_run / ebm_run_fused with diag_last, the seasonal and last steps of
+ * ebm_integrate).  A read of one of them — ebm_get_field, ebm_get_field_device, ebm_hemispheric_mean*,
+ * ebm_field_device_ptr — while the state is NEWER than the field (steps taken since without diagnostics, or
+ * a prognostic field overwritten with ebm_set_field) fails with EBM_ERR_STALE; the message names the step
+ * that last wrote the field and the state's step.  Nothing stale is ever returned silently — in particular
+ * not the T0 a caller would checkpoint as the warm start (src/miz.jl:47,64).  ebm_field_step reports both
+ * steps; ebm_get_field_as_of returns the field as of an EXPLICITLY named step (the 0-based global index of
+ * the step that wrote it) however far the state has moved on since, and fails with EBM_ERR_STALE if that is
+ * not the step that wrote it.  ebm_set_field(EBM_F_T0) makes T0 current; setting a diagnostic field directly
+ * makes that field current as well (it is the caller's statement of what it holds). */
 int ebm_set_field(ebm_handle_t h, int field, const double *host);
 int ebm_get_field(ebm_handle_t h, int field, double *host);
+/* *written_step: 0-based global index of the step that last wrote the field (-1: never written; for a field
+ * set by the caller: the index of the last step taken before that, -1 if none); *state_step: the same for
+ * the prognostic state.  The field is current iff the two are equal and no prognostic field has been
+ * overwritten since (*current != 0).  Any output pointer may be NULL. */
+int ebm_field_step(ebm_handle_t h, int field, long long *written_step, long long *state_step, int *current);
+int ebm_get_field_as_of(ebm_handle_t h, int field, long long step, double *host);
 /* hemispheric_mean (src/utilities.jl:397-403) of a field, per column, reduced on the device in the
  * reference's summation order (bit-identical): out[ncol] on the host.  Ensemble diagnostics are
  * O(columns) instead of O(state).  Synchronous. */
@@ -123,7 +171,10 @@ int ebm_get_field_device(ebm_handle_t h, int field, double *dev_out);
  * Synchronous. */
 int ebm_diffusion(ebm_handle_t h, const double *temp, const double *base, double *out);
 /* Device pointer of a field and its row pitch in elements (>= nlat), for zero-copy users
- * (e.g. a torch tensor view).  The pointer stays valid until ebm_destroy. */
+ * (e.g. a torch tensor view).  The pointer stays valid until ebm_destroy.  For the MIZ diagnostic fields the view
+ * shows the field as of this call: steps that write them afterwards store them in a layout private to the library
+ * until the next read through this interface (call again after such a step).  Fails with EBM_ERR_STALE like
+ * ebm_get_field. */
 int ebm_field_device_ptr(ebm_handle_t h, int field, double **dptr, long long *pitch);
 /* Per-column forcing offset added to the per-step scalar forcing (forcing = f + fcol[col];
  * NULL clears it).  This is how ensemble members / longitudes get perturbed forcings — the
@@ -135,8 +186,9 @@ int ebm_set_column_forcing(ebm_handle_t h, const double *fcol);
  *     T < d1: base;  T < d2: base + up*(T - d1);  T < d3: peak;  T < d4: peak + down*(T - d3);  else cool
  * sched[ncol][9] = {base, peak, cool, up, down, d1, d2, d3, d4} (d = Forcing.domain[2..5]); NULL
  * clears.  T of 0-based global step n is st.T[n+1] = (2n+1)/(2 nt): ebm_run takes n from
- * first_step, ebm_integrate starts at n = 0, ebm_step uses and advances the handle's step clock
- * (ebm_set_step_clock).  Needs the time table (its length is nt).  The three contributions add:
+ * first_step, ebm_step and ebm_integrate use and advance the handle's step clock (0 after ebm_create, set by
+ * ebm_set_step_clock, left at the step after the last one by every stepping call — so a run chunked into several
+ * ebm_integrate calls of whole years sees the same model time as one call).  Needs the time table (its length is nt).  The three contributions add:
  * forcing = f + fcol[c] + schedule_c(T). */
 int ebm_set_column_schedule(ebm_handle_t h, const double *sched);
 int ebm_set_step_clock(ebm_handle_t h, long long step);
@@ -176,8 +228,13 @@ int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double
  * winter_inx/summer_inx are the 1-based in-year indices st.winter.inx / st.summer.inx.
  * f_steps[nt*dur] as in ebm_run.  `fields` must be solution variables (not the hidden EBM_F_T0),
  * each at most once.  savesol! runs inside the step kernel: one launch per step, the annual-mean
- * sums (crossmean, src/utilities.jl:390-395: summed per cell in step order) and the raw snapshot
- * are taken from the step's registers.  Synchronous. */
+ * sums and the raw snapshot are taken from the step's registers.  The annual mean is sum / nt with the sum
+ * taken per cell sequentially in step order; the reference's crossmean (src/utilities.jl:390-395) is
+ * Statistics.mean over the year's snapshots, i.e. Julia's pairwise, SIMD-reassociated sum — the two agree up to
+ * summation-order rounding (the parity tests hold avg to 1e-8 of the oracle's), not bit for bit.
+ * The time-of-year index starts at 1 (the call begins a year); model time (per-column schedules) continues from
+ * the handle's step clock.  Host output overlaps the stepping (device-to-device snapshot, then DMA through the
+ * handle's pinned ring on a stream of its own).  Synchronous: returns when all outputs are in the caller's arrays. */
 int ebm_integrate(ebm_handle_t h, int nt, int dur, const double *f_steps, int lastonly,
                   int winter_inx, int summer_inx, int nvars, const int *fields, double *raw,
                   double *winter, double *summer, double *avg);

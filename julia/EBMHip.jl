@@ -55,16 +55,31 @@ gridkind(::SpaceTime) = Cint(1)
 parvec(par::Collection{Float64}) =
     Float64[haskey(getfield(par, :dict), k) ? getproperty(par, k) : getproperty(default_parval, k) for k in PARAM_ORDER]
 
+# struct ebm_options (include/ebm_hip.h): launch options; the library reads no environment variable.
+struct EBMOptions
+    struct_bytes::Cint
+    cells_per_thread::Cint      # 0 = default (4); 2: twice the waves per meridian, for a few short meridians
+    use_graph::Cint             # -1 = by size
+    prefetch_cols::Cint         # -1 = default
+end
+EBMOptions(; cells_per_thread::Integer=0, use_graph::Integer=-1, prefetch_cols::Integer=-1) =
+    EBMOptions(Cint(sizeof(EBMOptions)), Cint(cells_per_thread), Cint(use_graph), Cint(prefetch_cols))
+
 # One ebm_handle_t.  Every ccall that passes `h.ptr` sits inside `GC.@preserve h`: the pointer alone
 # does not keep `h` alive, and its finalizer calls ebm_destroy.
 mutable struct Handle
     ptr::Ptr{Cvoid}
-    function Handle(model::Symbol, st::SpaceTime, par::Collection{Float64}; ncol::Int=1, device::Int=0)
+    function Handle(model::Symbol, st::SpaceTime, par::Collection{Float64}; ncol::Int=1, device::Int=0,
+                    cells_per_thread::Int=(ncol == 1 && st.nx <= 1536 && model !== :MIZ_IMEX) ? 2 : 0)
         haskey(MODEL, model) || throw(MethodError(Infrastructure.step!, (Val(model),)))   # as the reference: no such method
         out = Ref{Ptr{Cvoid}}(C_NULL)
-        check(ccall((:ebm_create, libebm), Cint,
-                    (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cint),
-                    out, MODEL[model], gridkind(st), st.nx, ncol, st.x, parvec(par), st.dt, device), "ebm_create")
+        # The reference's own shapes are ONE meridian: latency-bound, so two latitudes per thread.  Chosen here,
+        # explicitly — the library never derives its launch geometry from the number of columns, because the rounding
+        # of the tridiagonal solves depends on it (a member must give the same bits alone and in an ensemble).
+        opt = Ref(EBMOptions(cells_per_thread=cells_per_thread))
+        check(ccall((:ebm_create_ex, libebm), Cint,
+                    (Ref{Ptr{Cvoid}}, Cint, Cint, Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Cint, Ref{EBMOptions}),
+                    out, MODEL[model], gridkind(st), st.nx, ncol, st.x, parvec(par), st.dt, device, opt), "ebm_create_ex")
         h = new(out[])
         finalizer(destroy!, h)
         return h

@@ -206,6 +206,7 @@ _C2J = {  # C parameter type (normalised) -> the Julia ccall argument types that
     "const double*": {"Ptr{Cdouble}"}, "double*": {"Ptr{Cdouble}"}, "const int*": {"Ptr{Cint}"},
     "int*": {"Ptr{Cint}"}, "long long*": {"Ptr{Clonglong}"}, "long long": {"Clonglong"},
     "float*": {"Ptr{Cfloat}", "Ref{Cfloat}"}, "double**": {"Ptr{Ptr{Cdouble}}", "Ref{Ptr{Cdouble}}"},
+    "const ebm_options*": {"Ref{EBMOptions}", "Ptr{EBMOptions}"}, "ebm_options*": {"Ref{EBMOptions}", "Ptr{EBMOptions}"},
 }
 
 
@@ -266,7 +267,7 @@ def test_julia_shim_ccalls_match_the_header():
     protos = _header_prototypes()
     assert "ebm_integrate" in protos and len(protos["ebm_integrate"][1]) == 13
     calls = _julia_ccalls()
-    assert {c[0] for c in calls} >= {"ebm_create", "ebm_destroy", "ebm_set_field", "ebm_get_field", "ebm_step",
+    assert {c[0] for c in calls} >= {"ebm_create_ex", "ebm_destroy", "ebm_set_field", "ebm_get_field", "ebm_step",
                                     "ebm_set_time_table", "ebm_integrate", "ebm_get_counters", "ebm_last_error",
                                     "ebm_set_column_schedule"}
     for name, ret, types, args in calls:
@@ -277,6 +278,23 @@ def test_julia_shim_ccalls_match_the_header():
         assert len(args) == len(types), f"{name}: {len(args)} arguments for {len(types)} parameter types"
         for jt, ct in zip(types, cparams):
             assert jt in _C2J[ct], f"{name}: Julia {jt} does not bind C {ct}"
+
+
+def test_julia_shim_options_struct_matches_the_header(pkg):
+    """struct ebm_options in the header, EBMOptions in the shim and Options in the ctypes binding: the same
+    fields, all int, in the same order."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ebm_hip.h")).read(), flags=re.S)
+    body = re.search(r"typedef struct ebm_options \{(.*?)\} ebm_options;", hdr, flags=re.S).group(1)
+    cfields = re.findall(r"\bint\s+([a-z_]+)\s*;", body)
+    assert cfields and len(cfields) == len([l for l in body.split(";") if l.strip()])
+    jl = open(os.path.join(ROOT, "julia", "EBMHip.jl")).read()
+    jbody = re.search(r"struct EBMOptions\n(.*?)\nend", jl, flags=re.S).group(1)
+    jfields = re.findall(r"^\s*([a-z_]+)::Cint", jbody, flags=re.M)
+    import sys
+    lib = sys.modules[pkg.__name__ + "._lib"]
+    pfields = [n for n, t in lib.Options._fields_]
+    assert cfields == jfields == pfields
+    assert all(t is ctypes.c_int for _, t in lib.Options._fields_)
 
 
 def test_julia_shim_enums_match_the_header():
