@@ -372,6 +372,7 @@ int check_current(const ebm_ctx *h, int f, const char *who) {
     if (!is_diagnostic(h, f) || h->written_epoch[f] == h->epoch) return EBM_OK;
     std::string msg = std::string(who) + ": field " + field_name(f) + " is stale — ";
     if (h->written_epoch[f] < 0) msg += "it has never been written";
+    else if (h->written_step[f] < 0) msg += "it holds what it held before the first step";
     else msg += "last written by step " + std::to_string(h->written_step[f]);
     msg += "; the state is at step " + std::to_string(h->state_step) +
            (h->written_step[f] == h->state_step && h->written_epoch[f] >= 0 ? " with prognostic fields overwritten since" : "") +

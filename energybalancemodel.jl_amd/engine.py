@@ -219,18 +219,32 @@ class Engine:
                   "ebm_run")
 
     def integrate(self, nt, dur, f_steps, lastonly, winter_inx, summer_inx, names,
-                  want_raw=True, want_seasonal=True, want_avg=True):
+                  want_raw=True, want_seasonal=True, want_avg=True, out=None):
         """ebm_integrate: returns dict(raw, winter, summer, avg), each [nvars, n, ncol, nlat].
         Outputs that are not wanted are None; with neither raw nor avg the diagnostic fields are
-        only written on the steps whose snapshot is taken."""
+        only written on the steps whose snapshot is taken.  ``out``: a dict returned by an earlier call of the
+        same shape, whose arrays are filled again instead of allocating new ones (a caller that integrates year
+        after year into the same buffers)."""
         nv = len(names)
         fields = (C.c_int * nv)(*[FIELD[n] for n in names])
         nraw = nt if lastonly else nt * dur
         f = None if f_steps is None else as_f64(f_steps, (nt * dur,))
-        raw = np.empty((nv, nraw, self.ncol, self.nlat)) if want_raw else None
-        def mk(wanted):
-            return np.full((nv, dur, self.ncol, self.nlat), np.nan) if wanted else None
-        winter, summer, avg = mk(want_seasonal), mk(want_seasonal), mk(want_avg)
+        shape = (nv, dur, self.ncol, self.nlat)
+
+        def reuse(key, wanted, shp):
+            a = None if out is None else out.get(key)
+            if not wanted:
+                return None
+            if a is not None and (a.shape != shp or a.dtype != np.float64 or not a.flags.c_contiguous):
+                raise ValueError(f"out[{key!r}] must be a C-contiguous float64 array of shape {shp}")
+            return a
+        raw = reuse("raw", want_raw, (nv, nraw, self.ncol, self.nlat))
+        if want_raw and raw is None:
+            raw = np.empty((nv, nraw, self.ncol, self.nlat))
+        def mk(key, wanted):
+            a = reuse(key, wanted, shape)
+            return a if (a is not None or not wanted) else np.full(shape, np.nan)
+        winter, summer, avg = mk("winter", want_seasonal), mk("summer", want_seasonal), mk("avg", want_avg)
         check(self.lib.ebm_integrate(self._h, nt, dur, dptr(f), int(lastonly), int(winter_inx),
                                      int(summer_inx), nv, fields, dptr(raw), dptr(winter),
                                      dptr(summer), dptr(avg)), "ebm_integrate")

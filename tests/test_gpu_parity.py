@@ -1280,8 +1280,23 @@ def test_tiny_and_odd_sizes_through_every_entry_point(pkg, coracle, nlat):
             if model != "Classic":
                 assert np.array_equal(got["run"][k], got["run_window"][k], equal_nan=True), (model, kind, k)
         worst = max(scaled_err(got["run"][k], ref[k]) for k in names)
-        record_error(f"tiny sizes: {model} {kind} {nlat} cells, 25 steps", "all fields", worst, 1e-10)
-        assert worst <= 1e-10, (model, kind, worst)                  # measured: <= 8.4e-11 (identity grid, 127 / 129 cells), else <= 1e-12
+        # Bar: 1e-10 — unless the model itself amplifies rounding beyond that over these 25 steps, which the oracle's own
+        # 80-bit build measures (same source, same fp64 inputs, ~2000x less rounding in between: how far the fp64 ORACLE is
+        # from the exactly evaluated discrete model).  On the identity grid at 127 / 129 cells the freeze-up front does:
+        # both fp64 paths sit ~1e-10 from the 80-bit result, GPU-vs-oracle 8e-11 (two cells per thread) / 1.2e-10 (four).
+        bar = 1e-10
+        if model != "Classic":
+            import __graft_entry__ as graft
+            ld = graft.load_oracle()[1].COracle(extended=True)
+            ext = {k: v.copy() for k, v in state.items()}
+            dl, _ = ld.miz_run(0 if kind == "identity" else 1, st.x, dict(par), st.dt, ct[40:40 + nsteps], np.zeros(nsteps), fcol, ext,
+                               imex=(model == "MIZ_IMEX"))
+            ext.update(dl)
+            amp = max(scaled_err(ref[k], ext[k]) for k in names)
+            record_error(f"tiny sizes: {model} {kind} {nlat} cells, 25 steps: oracle vs 80-bit", "all fields", amp, float("nan"))
+            bar = max(bar, 3.0 * amp)
+        record_error(f"tiny sizes: {model} {kind} {nlat} cells, 25 steps", "all fields", worst, bar)
+        assert worst <= bar, (model, kind, worst, bar)
 
 
 @pytest.mark.parametrize("seed", range(8))
