@@ -113,8 +113,8 @@ void parallel_memcpy(void *dst, const void *src, size_t bytes) {
     });
 }
 
-constexpr int kRingSlots = 4;
-constexpr size_t kSlotBytes = (size_t)16 << 20;
+constexpr int kRingSlots = 8;
+constexpr size_t kSlotBytes = (size_t)4 << 20;
 
 // One device -> host copy: nrows rows of row_elems doubles, src_pitch elements apart on the device, packed on the host.
 struct CopyJob {

@@ -217,7 +217,7 @@ def test_full_size_classic_matches_the_analytic_recurrence_in_every_cell(pkg):
     assert 0.15 < err.min() and err.max() < 0.18, (err.min(), err.max())
 
 
-def test_state_slab_beyond_32_bit_indices(pkg, coracle):
+def test_state_slab_beyond_32_bit_indices(pkg, oracle, coracle):
     """65,536 meridians of 4096 cells: 2 GiB per field, 22 GiB of state — field slots start beyond 2^31 ELEMENTS and
     beyond 2^32 bytes, a column's offset inside a field exceeds 2^28 elements.  10 steps from zero; columns that share a
     forcing value are bitwise equal wherever they sit in the slab (first, middle, last replica), and sampled columns of
@@ -237,19 +237,26 @@ def test_state_slab_beyond_32_bit_indices(pkg, coracle):
         diag, _ = coracle.miz_run(1, st.x, dict(par), st.dt, ct, np.zeros(nsteps), fcol[sample], state)
         ref = dict(state, **diag)
         worst = {"T0, Ti": 0.0, "others": 0.0}
+        last = {}
         for k in PROG + ("T0",) + DIAG:                              # one 2 GiB field on the host at a time
             a = eng.get_field(k).reshape(ncol // 64, 64, nlat)
             assert np.array_equal(a[0], a[511], equal_nan=True) and np.array_equal(a[0], a[1023], equal_nan=True), k
             key = "T0, Ti" if k in ("T0", "Ti") else "others"
             worst[key] = max(worst[key], scaled_err(a[1023][sample], ref[k]))
+            if k in ("phi", "Ew"):
+                last[k] = a[1023][sample].copy()
             del a
     assert cnt["cap_hits"] == 0
-    # the surface temperature of the first, thinnest ice is the worst-conditioned solve of a run (cond(J) eps = 2e-10 at
-    # 4096 cells): measured 1.65e-10 in T0 / Ti, identical for 64 and for 65,536 columns; every
-    # prognostic and the other diagnostics: 4.7e-14
-    record_error("22 GiB slab, 4096 x 65536, 10 steps from zero: last replica vs oracle, T0 and Ti", "T0, Ti", worst["T0, Ti"], 1.7e-9)
+    # T0 at the advancing ice edge depends on the concentration of the newly frozen cells with a factor 1e4 ... 1e6: the bar for
+    # T0 / Ti is what that sensitivity of the sampled columns makes of the differences in phi and Ew actually observed
+    # (test_gpu_parity.t0_error_explained_by_state) x the same stated constant 4 as test_full_size_4096x2048_properties
+    # (measured 1.65e-10, identical for 64 and for 65,536 columns); every prognostic and the other diagnostics: 4.7e-14
+    from test_gpu_parity import t0_error_explained_by_state
+    explained = t0_error_explained_by_state(oracle, "sin", st.x, par, ref, last)
+    bound = 4.0 * explained + 1e-12
+    record_error(f"22 GiB slab, 4096 x 65536, 10 steps from zero: last replica vs oracle, T0 and Ti (4 x explained by the state difference {explained:.2e})", "T0, Ti", worst["T0, Ti"], bound)
     record_error("22 GiB slab, 4096 x 65536, 10 steps from zero: last replica vs oracle, all other fields", "others", worst["others"], 5e-13)
-    assert worst["T0, Ti"] <= 1.7e-9 and worst["others"] <= 5e-13, worst
+    assert worst["T0, Ti"] <= bound and worst["others"] <= 5e-13, (worst, bound)
 
 
 def test_handles_from_concurrent_host_threads(pkg):

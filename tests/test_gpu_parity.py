@@ -10,10 +10,17 @@ as profiles/r02_measured_errors.jsonl) and its bar is
 
     bar = min(10 x the error measured on MI355X, the bar BASELINE.json / the reference test gives)
 
-with the measured value written next to it.  No bar exceeds 1e-10 — BASELINE.json's figure and two
-orders inside the reference test's own isapprox rtol 1.49e-8 (test/runtests.jl:46) — except the
-year-long run on the identity grid (TOL_YEAR) and the shadowing tests, whose bars come from the
-oracle's own sensitivity.  profiles/r02_error_budget.txt adds, per configuration, how far the GPU and
+with the measured value written next to it.  Bars are at most 1e-10 — BASELINE.json's figure, two
+orders inside the reference test's own isapprox rtol 1.49e-8 (test/runtests.jl:46) — with these stated
+exceptions, each explained where it is used: (1) T0 / Ti of 4096-cell meridians during the first tens of steps
+from the zero state, where T0 is extremely sensitive to the concentration of the newly frozen cells at the ice
+edge: the bar is what that sensitivity, computed in the test cell by cell from the columns' own h, phi and T0,
+makes of the differences in phi and Ew actually observed (t0_error_explained_by_state below), times a stated constant (measured 2.0e-10 at step 10,
+2.2e-9 at step 20 while every other field is below 1e-12; the same bar in tests/test_gpu_configs.py);
+(2) the implicit-diffusion extension at time steps hundreds of times beyond the explicit limit (<= 9e-10,
+tests/test_gpu_imex.py); (3) trajectories the model itself amplifies beyond 1e-10, where the bar is a multiple
+of the fp64 oracle's own distance from its 80-bit build (tiny sizes on the identity grid) or of the oracle's
+4-ulp envelope (the shadowing tests, the year-long run on the identity grid, TOL_YEAR).  profiles/r02_error_budget.txt adds, per configuration, how far the GPU and
 the fp64 oracle EACH are from the same model evaluated in 80-bit extended precision: the GPU is as
 close to it as the oracle is (test_gpu_error_budget.py).
 Long trajectories: the reference's own test configuration (sin grid, nx = 180, nt = 2000) is
@@ -53,6 +60,38 @@ def check_all(got, ref, tol, names=ALL, what=""):
     record_error(what, worst, errs[worst], tol)
     for k in names:
         assert errs[k] <= tol, f"{what}: {k} scaled error {errs[k]:.3e} > {tol:.1e}"
+
+
+def t0_error_explained_by_state(oracle, kind, x, par, ref, got):
+    """What the observed difference between two runs' STATES (phi, Ew) makes of their T0, cell by cell.
+
+    Row k of the T0 system (src/miz.jl:33-45) reads  -(k/h' + B) v_k + Dif(phi [v<0] v)_k = -(ai S - A + Dif((1-phi)(Tw-Tm))_k + f),
+    v = T0 - Tm, Dif_k(u) = lo_k u_{k-1} - (lo_k + up_k) u_k + up_k u_{k+1} with lo + up ~ 0.81 D nlat^2 (1.4e7 at 4096
+    latitudes) — over a diagonal of only k/hmin + B = 22 where new ice is thin and sparse.  A change of phi or of
+    r = (1-phi)(Tw-Tm) = Ew/cw in cells k-1 ... k+1 therefore moves v_k by up to
+        (lo_k + up_k) (|v_k| [v_k<0] |dphi| + |dEw|/cw) / (k/h'_k + B + (lo_k + up_k) phi_k [v_k<0]):
+    1e4 ... 1e6 kelvin per unit of concentration at the advancing ice edge of a freeze-up.  The newly frozen cells' enthalpy
+    is the small remainder of the water's, so its rounding is relatively large: two runs differ by ~1e-14 in phi there, hence
+    by ~1e-10 in T0 — in any arithmetic (checked on the CPU: the fp64 oracle against its own 80-bit build, 180 ... 4096
+    latitudes, both grids, steps 5 ... 60: the observed T0 difference is 0.1 ... 1.8 x this expression).
+    `ref`, `got`: dicts of [ncol, nlat] arrays h, phi, T0, Ew (the state a step ends with stands in for the one the next
+    begins with).  Returns the maximum over cells and columns."""
+    geom = oracle.DiffusionGeometry("identity" if kind == "identity" else "sin", x, par["D"])
+    lu = geom.lo + geom.up
+
+    def nbr(d):                      # max over cells k-1, k, k+1
+        e = np.concatenate(([0.0], np.abs(d), [0.0]))
+        return np.maximum(np.maximum(e[:-2], e[1:-1]), e[2:])
+    worst = 0.0
+    for i in range(ref["phi"].shape[0]):
+        hp = np.where(ref["h"][i] == 0.0, par["hmin"], ref["h"][i])
+        dd = par["k"] / hp + par["B"]
+        v = np.abs(ref["T0"][i] - par["Tm"])
+        act = (ref["T0"][i] < par["Tm"]).astype(float)
+        dphi = nbr(got["phi"][i] - ref["phi"][i])
+        dr = nbr((got["Ew"][i] - ref["Ew"][i]) / par["cw"])
+        worst = max(worst, float(np.max(lu * (v * act * dphi + dr) / (dd + lu * ref["phi"][i] * act))))
+    return worst
 
 
 # ---- golden fixtures: the reference test's configuration -------------------------------------
@@ -169,7 +208,7 @@ def test_headline_meridians_shadow_the_oracle(pkg, coracle):
         eng.set_column_forcing(fcol)
         eng.set_time_table(st.t)
         done = 0
-        for s in (20, 50, 200, 500, 1000):
+        for s in (10, 20, 50, 200, 500, 1000):
             n = s - done
             coracle.miz_run(1, st.x, dict(par), st.dt, ct[done:s], np.zeros(n), fcol, ref)
             coracle.miz_run(1, st.x, pert, st.dt, ct[done:s], np.zeros(n), fcol, alt)
@@ -178,8 +217,10 @@ def test_headline_meridians_shadow_the_oracle(pkg, coracle):
             got = eng.get_state(PROG)
             dist = max(scaled_err(got[k], ref[k]) for k in PROG)
             envelope = max(scaled_err(alt[k], ref[k]) for k in PROG)
-            record_error(f"headline shadow step {s} (envelope {envelope:.2e})", "PROG", dist, max(TOL_SHORT, 5.0 * envelope))
-            assert dist <= max(TOL_SHORT, 5.0 * envelope), f"step {s}: {dist:.2e} vs {envelope:.2e}"
+            # the first tens of steps are not yet in the sensitive regime: there the prognostics must agree to 1e-12 outright
+            bar = 1e-12 if s <= 20 else max(TOL_SHORT, 5.0 * envelope)
+            record_error(f"headline shadow step {s} (envelope {envelope:.2e})", "PROG", dist, bar)
+            assert dist <= bar, f"step {s}: {dist:.2e} vs {envelope:.2e}"
         assert eng.counters()["cap_hits"] == 0
 
 
@@ -198,7 +239,50 @@ def test_t0_meets_reference_solver_criterion(pkg, coracle):
             T0 = eng.get_field("T0")[0]
         res = coracle.T0eq(1, st.x, dict(par), pkg.cos2pit(float(st.t[s])), 0.0,
                            g[f"s{s}_h"], g[f"s{s}_Ew"], g[f"s{s}_phi"], T0)
+        record_error(f"|T0eq(T0_gpu)| at 180 cells, step {s}", "T0eq", float(np.max(np.abs(res))), 1e-8)
         assert np.max(np.abs(res)) < 1e-8, (s, float(np.max(np.abs(res))))
+
+
+@pytest.mark.parametrize("nlat,nt,steps", [(1440, 131072, (10, 20, 60)), (4096, 1048576, (10, 20, 40))])
+def test_t0_meets_reference_solver_criterion_at_high_resolution(pkg, coracle, nlat, nt, steps):
+    """The same acceptance test where the T0 system is 60 ... 500 times worse conditioned than at 180 cells (BASELINE
+    configs[1] and [3]; cond(J) grows with nlat^2): from the oracle's state at steps 10 / 20 / 40-60 of the freeze-up
+    the GPU takes one step and its T0 is put into the reference's residual function (a transcription of T0eq,
+    src/miz.jl:33-45, evaluated by the checker in fp64 AND in 80-bit extended precision).
+
+    Measured on MI355X: 1.0e-10 ... 5.6e-10 at 1440 cells and 9.7e-11 ... 4.1e-10 at 4096 cells, in fp64 and in 80-bit
+    evaluation alike, and the same figures for the oracle's own T0 — twenty times inside abstol; the residual function's own
+    rounding noise stays below that as well (the 80-bit and fp64 evaluations of the same T0 differ by < 1e-10)."""
+    import __graft_entry__ as graft
+    ld = graft.load_oracle()[1].COracle(extended=True)
+    st = pkg.SpaceTime("sin", nlat, nt, 1)
+    par = pkg.default_parameters("MIZ")
+    ct = ctab(pkg, st)
+    fcol = np.array([0.0, 0.5])
+    state = {k: np.zeros((2, nlat)) for k in PROG + ("T0",)}
+    done = 0
+    for s in steps:
+        coracle.miz_run(1, st.x, dict(par), st.dt, ct[done:s], np.zeros(s - done), fcol, state)
+        done = s
+        with make_engine(pkg, "MIZ", st, par, 2) as eng:
+            eng.set_column_forcing(fcol)
+            eng.set_time_table(st.t)
+            eng.set_state(state)
+            eng.run(s, 1)
+            T0_gpu = eng.get_field("T0")
+        nxt = {k: v.copy() for k, v in state.items()}
+        coracle.miz_run(1, st.x, dict(par), st.dt, ct[s:s + 1], np.zeros(1), fcol, nxt)
+        worst = {"gpu": 0.0, "gpu_ld": 0.0, "oracle": 0.0}
+        for c in range(2):
+            args = (1, st.x, dict(par), float(ct[s]), float(fcol[c]), state["h"][c], state["Ew"][c], state["phi"][c])
+            worst["gpu"] = max(worst["gpu"], float(np.max(np.abs(coracle.T0eq(*args, T0_gpu[c])))))
+            worst["gpu_ld"] = max(worst["gpu_ld"], float(np.max(np.abs(ld.T0eq(*args, T0_gpu[c])))))
+            worst["oracle"] = max(worst["oracle"], float(np.max(np.abs(coracle.T0eq(*args, nxt["T0"][c])))))
+        record_error(f"|T0eq(T0_gpu)| at {nlat} cells, step {s}: 80-bit evaluation", "T0eq", worst["gpu_ld"], 1e-8)
+        record_error(f"|T0eq(T0_gpu)| at {nlat} cells, step {s}: fp64 evaluation (oracle's own T0: {worst['oracle']:.2e})", "T0eq",
+                     worst["gpu"], 1e-8)
+        assert worst["gpu_ld"] <= 1e-8 and worst["gpu"] <= 1e-8, (s, worst)
+        assert np.any(state["phi"] > 0)
 
 
 @pytest.mark.parametrize("kind,nlat,nt", [("identity", 1024, 131072), ("sin", 4096, 1048576)])
@@ -797,32 +881,53 @@ def test_integrate_classic_surface(pkg, oracle):
 
 
 # ---- BASELINE.json full size: size-independent properties ---------------------------------------
-def test_full_size_4096x2048_properties(pkg, coracle):
-    """configs[3] at full size (4096 x 2048, 384 MiB of state): (1) 32 sampled columns agree
-    with the oracle after spin-up + steps, (2) columns with equal forcing are bitwise equal,
-    (3) the active-set iteration never hits its cap."""
+def test_full_size_4096x2048_properties(pkg, oracle, coracle):
+    """configs[3] at full size (4096 x 2048, 384 MiB of state): (1) 32 sampled columns agree with the oracle at steps
+    10, 20 and 40 from the zero state — the prognostics, which carry the run, to 1e-12; T0, Ti and the temperatures
+    formed from them within what the columns' own sensitivity dT0/dphi makes of the observed difference in phi
+    and Ew (t0_error_explained_by_state: during the first tens of steps T0 at the advancing ice edge depends on the
+    concentration of the newly frozen cells with a factor 1e4 ... 1e6 — the fp64 oracle itself is 1.6e-8 from its own 80-bit
+    evaluation there), (2) columns with equal forcing are bitwise equal, (3) the
+    active-set iteration never hits its cap."""
     nlat, ncol, nt = 4096, 2048, 1048576
     st = pkg.SpaceTime("sin", nlat, nt, 1)
     par = pkg.default_parameters("MIZ")
     fcol = 0.5 * np.sin(2.0 * np.pi * (np.arange(ncol) % 64) / 64)       # 32 replicas of 64 forcings
-    nsteps = 40
+    sample = np.arange(0, 64, 2)
+    state = {k: np.zeros((len(sample), nlat)) for k in PROG + ("T0",)}
+    ct = ctab(pkg, st)
+    SOLVE = ("T0", "Ti", "T")             # what the T0 solve enters directly; everything else only through the dynamics
+    # Bar for T0 / Ti / T: 4 x what the columns' own sensitivity makes of the observed state difference, + 1e-12.  The stated
+    # constant 4 covers that the state a step ENDS with stands in for the one it began with (on the CPU, oracle against
+    # its 80-bit build, the observed T0 difference is at most 1.8 x the expression); the ratios on MI355X are recorded.
+    CONST = 4.0
     with make_engine(pkg, "MIZ", st, par, ncol) as eng:
         eng.set_column_forcing(fcol)
         eng.set_time_table(st.t)
-        eng.run(0, nsteps)
-        got = eng.get_state(ALL)
+        done = 0
+        for s_ in (10, 20, 40):
+            eng.run(done, s_ - done)
+            got = eng.get_state(ALL)
+            diag, _ = coracle.miz_run(1, st.x, dict(par), st.dt, ct[done:s_], np.zeros(s_ - done), fcol[sample], state)
+            done = s_
+            ref = dict(state)
+            ref.update(diag)
+            sub = {k: got[k][sample] for k in ALL}
+            errs = {k: scaled_err(sub[k], ref[k]) for k in ALL}
+            explained = t0_error_explained_by_state(oracle, "sin", st.x, par, ref, sub)
+            bar = CONST * explained + 1e-12
+            solve_err = max(errs[k] for k in SOLVE)
+            other = max(errs[k] for k in ALL if k not in SOLVE)
+            record_error(f"4096x2048 sample, step {s_}: T0/Ti/T; explained by the observed state difference: {explained:.2e} "
+                         f"(ratio {solve_err / max(explained, 1e-300):.2f})", max(SOLVE, key=errs.get), solve_err, bar)
+            record_error(f"4096x2048 sample, step {s_}: every other field", max((k for k in ALL if k not in SOLVE), key=errs.get), other, 1e-12)
+            assert solve_err <= bar, (s_, solve_err, explained)
+            assert other <= 1e-12, (s_, errs)
         cnt = eng.counters()
     assert cnt["cap_hits"] == 0
     for k in ALL:
         a = got[k].reshape(32, 64, nlat)
         assert np.array_equal(a[0], a[17], equal_nan=True) and np.array_equal(a[0], a[31], equal_nan=True), k
-    sample = np.arange(0, 64, 2)
-    state = {k: np.zeros((len(sample), nlat)) for k in PROG + ("T0",)}
-    ct = ctab(pkg, st)[:nsteps]
-    diag, _ = coracle.miz_run(1, st.x, dict(par), st.dt, ct, np.zeros(nsteps), fcol[sample], state)
-    ref = dict(state)
-    ref.update(diag)
-    check_all({k: got[k][sample] for k in ALL}, ref, 2e-11, what="4096x2048 sample")      # measured 2.0e-12
 
 
 # ---- an anchor outside the oracle: the analytic Legendre-mode decay (tests/test_analytic_solutions.py) ------------
