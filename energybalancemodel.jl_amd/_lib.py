@@ -25,7 +25,7 @@ PARAM_ORDER = ("D", "A", "B", "cw", "S0", "S1", "S2", "a0", "a2", "ai", "Fb", "k
 EXPORTS = (
     "ebm_create", "ebm_create_ex", "ebm_options_default", "ebm_field_step", "ebm_get_field_as_of", "ebm_destroy", "ebm_last_error", "ebm_version", "ebm_set_field",
     "ebm_get_field", "ebm_hemispheric_mean", "ebm_hemispheric_mean_device", "ebm_get_field_device",
-    "ebm_field_device_ptr", "ebm_diffusion", "ebm_set_column_forcing", "ebm_set_column_schedule",
+    "ebm_field_device_ptr", "ebm_diffusion", "ebm_zonal_diffusion", "ebm_set_column_forcing", "ebm_set_column_schedule",
     "ebm_set_step_clock", "ebm_set_time_table",
     "ebm_step", "ebm_run", "ebm_run_fused", "ebm_integrate", "ebm_integrate_hemispheric", "ebm_sync", "ebm_get_counters",
     "ebm_reset_counters", "ebm_timer_start", "ebm_timer_stop", "ebm_launch_info",
@@ -89,6 +89,7 @@ def load():
     lib.ebm_hemispheric_mean_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.ebm_get_field_device.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.ebm_diffusion.argtypes = [C.c_void_p, _dp, _dp, _dp]
+    lib.ebm_zonal_diffusion.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp]
     lib.ebm_field_device_ptr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p),
                                          C.POINTER(C.c_longlong)]
     lib.ebm_set_column_forcing.argtypes = [C.c_void_p, _dp]

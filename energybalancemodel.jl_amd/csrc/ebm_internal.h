@@ -135,6 +135,16 @@ hipError_t launch_diffusion(const double *temp, const double *base, double *out,
 // layout of the step kernels, then sum = 0; all nvars variables (var_stride apart) in one launch
 hipError_t launch_finish_mean(double *dst, double *sum, double nt, int ncol, int nvars, long long var_stride,
                               const LaunchCfg &cfg, hipStream_t s);
+// Zonal diffusion substep (ebm_zonal_diffusion): per member and latitude the periodic tridiagonal solve along the circle.
+// Everything lives in the handle's store index space p (4 cells per thread: pair-split, p = j*2T + 2t + q <-> latitude
+// k = 4t + 2j + q; 2 cells per thread: p = k), so that all accesses are contiguous: T, out_Z, out_U [ncol][pitch];
+// zM, zE [nlon][pitch]; za, zW [pitch].  out_Z is also the scratch of the forward sweep; out_U may be null.
+hipError_t launch_zonal_sweep(const double *T, double *out_Z, double *out_U, const double *zM, const double *zE,
+                              const double *za, const double *zW, int nlon, int nmember, int pitch, double rtheta,
+                              hipStream_t s);
+// natural <-> pair-split layout of whole fields ([ncol][pitch], 4 cells per thread; a no-op with 2), in place
+hipError_t launch_split_fields(double *fields, long long field_stride, int nfields, int ncol, const LaunchCfg &cfg,
+                               hipStream_t s);
 // the diagnostic fields of a 4-cells-per-thread step launch, pair-split -> natural layout, in place
 hipError_t launch_unsplit_fields(double *fields, long long field_stride, int nfields, int ncol, const LaunchCfg &cfg,
                                  hipStream_t s);

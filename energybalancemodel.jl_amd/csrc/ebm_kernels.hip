@@ -1319,6 +1319,124 @@ __global__ void unsplit_fields_kernel(double *__restrict__ fields, long long fie
     *reinterpret_cast<double2 *>(f + 4 * t) = p0;
     *reinterpret_cast<double2 *>(f + 4 * t + 2) = p1;
 }
+// natural -> pair-split, the inverse (a field the caller set, about to be read by a kernel that expects the split layout)
+__global__ void split_fields_kernel(double *__restrict__ fields, long long field_stride, int threads) {
+    const int t = threadIdx.x;
+    double *f = fields + (size_t)blockIdx.y * (size_t)field_stride + (size_t)blockIdx.x * (size_t)threads * 4;
+    const double2 p0 = *reinterpret_cast<const double2 *>(f + 4 * t);
+    const double2 p1 = *reinterpret_cast<const double2 *>(f + 4 * t + 2);
+    __syncthreads();
+    *reinterpret_cast<double2 *>(f + 2 * t) = p0;
+    *reinterpret_cast<double2 *>(f + 2 * threads + 2 * t) = p1;
+}
+hipError_t launch_split_fields(double *fields, long long field_stride, int nfields, int ncol, const LaunchCfg &cfg,
+                               hipStream_t s) {
+    if (cfg.cells != 4) return hipSuccess;
+    split_fields_kernel<<<dim3(ncol, nfields), cfg.threads, 0, s>>>(fields, field_stride, cfg.threads);
+    return hipGetLastError();
+}
+
+// ---- the zonal diffusion operator as a backward-Euler substep (ebm_zonal_diffusion: an extension, defined in include/ebm_hip.h) ----
+// One lane per (member, latitude): the nlon unknowns of a latitude circle are walked sequentially, so that every access
+// of a wave is along the contiguous latitude axis (in the pair-split index space: lane p of the row of longitude l reads
+// T[(member*nlon + l)*pitch + p]).  Periodic tridiagonal system B U_l - a (U_{l-1} + U_{l+1}) = b_l, B = 1 + 2a, by Thomas
+// elimination that carries the coupling to the LAST unknown W = U_{n-1} along (no Sherman-Morrison second solve):
+//     U_l = cp_l U_{l+1} + ep_l W + dp_l,     cp_l = a m_l,  ep_l = a ep_{l-1} m_l,  m_l = 1/(B - a cp_{l-1}),
+//     dp_l = (b_l + a dp_{l-1}) m_l            (the only data-dependent recurrence: one fma and one multiply per unknown)
+// while the last row is reduced alongside: its coefficient on U_l is f_l = -a ep_{l-1} (f_0 = -a), its right-hand side
+// collects R = -sum f_l dp_l; W = (b_{n-1} + R - (f_{n-2} - a) dp_{n-2}) zW with zW the reciprocal of the reduced
+// diagonal.  m_l, ep_l and zW depend on (latitude, l) only and come from tables built at ebm_create (zM, zE, zW); a = za.
+// Forward sweep: dp_l is parked in the output array; backward sweep: U_l, then Z_l = (U_l - b_l) cw/dt over it.
+// Free arithmetic (fma): the result is defined by the linear system.  UNR rows are loaded ahead of the recurrence.
+template <int UNR>
+__global__ void __launch_bounds__(256) zonal_sweep_kernel(const double *__restrict__ T, double *__restrict__ out_Z,
+                                                          double *__restrict__ out_U, const double *__restrict__ zM,
+                                                          const double *__restrict__ zE, const double *__restrict__ za,
+                                                          const double *__restrict__ zW, int nlon, int pitch, double rtheta) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= pitch) return;
+    const size_t row0 = (size_t)blockIdx.y * (size_t)nlon * (size_t)pitch + (size_t)p;
+    const double *b = T + row0;
+    double *d = out_Z + row0;
+    double *u = out_U ? out_U + row0 : nullptr;
+    const double *M = zM + p, *E = zE + p;
+    const double a = za[p];
+    const size_t P = (size_t)pitch;
+    const int n = nlon;
+    // ---- forward: l = 0 .. n-2 ----
+    double dp = b[0] * M[0];
+    double R = 0.0, f = -a;
+    int l = 0;
+    for (; l + UNR <= n - 2; l += UNR) {           // rows l+1 .. l+UNR are needed: all <= n-2
+        double bb[UNR], mm[UNR], ee[UNR];
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+            bb[i] = b[(size_t)(l + 1 + i) * P];
+            mm[i] = M[(size_t)(l + 1 + i) * P];
+            ee[i] = E[(size_t)(l + i) * P];
+        }
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+            d[(size_t)(l + i) * P] = dp;
+            R = __builtin_fma(-f, dp, R);
+            f = -a * ee[i];
+            dp = __builtin_fma(a, dp, bb[i]) * mm[i];
+        }
+    }
+    for (; l < n - 2; ++l) {
+        d[(size_t)l * P] = dp;
+        R = __builtin_fma(-f, dp, R);
+        f = -a * E[(size_t)l * P];
+        dp = __builtin_fma(a, dp, b[(size_t)(l + 1) * P]) * M[(size_t)(l + 1) * P];
+    }
+    // dp = dp_{n-2}, f = f_{n-2}
+    const double bl = b[(size_t)(n - 1) * P];
+    const double W = (bl + R - (f - a) * dp) * zW[p];
+    d[(size_t)(n - 1) * P] = (W - bl) * rtheta;
+    if (u) u[(size_t)(n - 1) * P] = W;
+    // ---- backward: l = n-2 .. 0 (dp_{n-2} is still in the register) ----
+    double Un = W;
+    l = n - 2;
+    {
+        const double U = __builtin_fma(a * M[(size_t)l * P], Un, __builtin_fma(E[(size_t)l * P], W, dp));
+        d[(size_t)l * P] = (U - b[(size_t)l * P]) * rtheta;
+        if (u) u[(size_t)l * P] = U;
+        Un = U;
+        --l;
+    }
+    for (; l - UNR + 1 >= 0; l -= UNR) {
+        double bb[UNR], mm[UNR], ee[UNR], dd[UNR];
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+            bb[i] = b[(size_t)(l - i) * P];
+            mm[i] = M[(size_t)(l - i) * P];
+            ee[i] = E[(size_t)(l - i) * P];
+            dd[i] = d[(size_t)(l - i) * P];
+        }
+#pragma unroll
+        for (int i = 0; i < UNR; ++i) {
+            const double U = __builtin_fma(a * mm[i], Un, __builtin_fma(ee[i], W, dd[i]));
+            d[(size_t)(l - i) * P] = (U - bb[i]) * rtheta;
+            if (u) u[(size_t)(l - i) * P] = U;
+            Un = U;
+        }
+    }
+    for (; l >= 0; --l) {
+        const double U = __builtin_fma(a * M[(size_t)l * P], Un, __builtin_fma(E[(size_t)l * P], W, d[(size_t)l * P]));
+        d[(size_t)l * P] = (U - b[(size_t)l * P]) * rtheta;
+        if (u) u[(size_t)l * P] = U;
+        Un = U;
+    }
+}
+hipError_t launch_zonal_sweep(const double *T, double *out_Z, double *out_U, const double *zM, const double *zE,
+                              const double *za, const double *zW, int nlon, int nmember, int pitch, double rtheta,
+                              hipStream_t s) {
+    // one wave per workgroup: as many workgroups as the (few) lanes of this kernel allow
+    dim3 grid((pitch + 63) / 64, nmember), block(64);
+    zonal_sweep_kernel<8><<<grid, block, 0, s>>>(T, out_Z, out_U, zM, zE, za, zW, nlon, pitch, rtheta);
+    return hipGetLastError();
+}
+
 hipError_t launch_unsplit_fields(double *fields, long long field_stride, int nfields, int ncol, const LaunchCfg &cfg,
                                  hipStream_t s) {
     if (cfg.cells != 4) return hipSuccess;               // two cells per thread: the layouts coincide

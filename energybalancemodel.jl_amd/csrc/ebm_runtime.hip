@@ -40,7 +40,7 @@ int fail(int code, const std::string &msg) {
 // ---- host transfers: pinned staging ring + a few host threads ---------------------------------------
 // The caller's buffers are pageable.  A device -> pageable copy through the runtime alone runs at 7-8 GB/s
 // (one thread faults the destination's pages in and copies); here the DMA engine fills a pinned slot while
-// the previous slot is copied on to the caller's buffer by kCopyThreads host threads.
+// the previous slot is copied on to the caller's buffer by the host threads of a small process-wide pool (up to 12).
 
 // Process-wide pool: parallel_for(n, fn) runs fn(i) for i in [0, n) on the pool's threads and returns when
 // all are done.  One caller at a time (callers serialise on `gate`).
@@ -71,7 +71,7 @@ public:
 private:
     HostPool() {
         unsigned hw = std::thread::hardware_concurrency();
-        int n = (int)std::min(8u, std::max(1u, hw));
+        int n = (int)std::min(12u, std::max(1u, hw));
         for (int i = 0; i < n; ++i) threads_.emplace_back([this] { run(); }), threads_.back().detach();
     }
     void run() {
@@ -113,8 +113,8 @@ void parallel_memcpy(void *dst, const void *src, size_t bytes) {
     });
 }
 
-constexpr int kRingSlots = 8;
-constexpr size_t kSlotBytes = (size_t)4 << 20;
+constexpr int kRingSlots = 4;
+constexpr size_t kSlotBytes = (size_t)16 << 20;
 
 // One device -> host copy: nrows rows of row_elems doubles, src_pitch elements apart on the device, packed on the host.
 struct CopyJob {
@@ -324,6 +324,10 @@ struct ebm_ctx {
     // 128-B lines per store instruction, csrc/ebm_kernels.hip); whoever reads one of them gets the natural layout:
     // the first reader after such a step runs the in-place un-permutation once.
     bool diag_split = false;
+    // ebm_zonal_diffusion: the tables of the last nlon used, kept between calls
+    int nlon = 0;
+    double *ztab = nullptr;                        // zM | zE ([nlon][pitch] each) | za | zW ([pitch] each), store index space
+    std::vector<double> xhost;                     // st.x (the zonal tables are built on demand)
     HostCopier *copier = nullptr;                  // pinned staging ring, lazily created by the first host transfer
     double *scratch = nullptr;                     // ebm_diffusion: temp | base | out, kept between calls
     // ebm_integrate's device buffers, kept between calls while the shape stays the same
@@ -478,6 +482,63 @@ void fill_params(ebm::Params &p, const double *v, double dt) {
     p.M = p.B + p.cg_tau;
     p.kLf = p.k * p.Lf;
     p.theta_imex = dt / p.cw;            // EBM_MODEL_MIZ_IMEX: the solve's matrix is I - theta*Dif
+}
+
+// Tables of the zonal substep (ebm_zonal_diffusion, include/ebm_hip.h; kernel: zonal_sweep_kernel): per latitude the
+// coefficient a_k = (dt/cw) D / ((1 - x_k)(1 + x_k) dlambda^2) and the data-independent part of the periodic Thomas
+// elimination (m_l, ep_l, the reciprocal of the reduced last diagonal), stored in the handle's store index space: with 4
+// cells per thread entry p = j*2T + 2t + q belongs to latitude k = 4t + 2j + q (pair-split), with 2 cells p = k; padding
+// latitudes get a = 0 (U = temp, Z = 0).  Built on first use and whenever nlon changes.
+int build_zonal_tables(ebm_ctx *h, int nlon) {
+    if (h->ztab && h->nlon == nlon) return EBM_OK;
+    const int n = nlon, P = (int)h->pitch, T = h->cfg.threads;
+    const double *x = h->xhost.data();
+    const double dl = 2.0 * M_PI / n, theta = h->dt / h->p.cw;
+    std::vector<double> tab((size_t)2 * n * P + 2 * (size_t)P, 0.0);
+    double *zM = tab.data(), *zE = zM + (size_t)n * P, *za = zE + (size_t)n * P, *zW = za + P;
+    for (int p = 0; p < P; ++p) {
+        int k = p;
+        if (h->cfg.cells == 4) {
+            const int j = p / (2 * T), rem = p % (2 * T), t = rem / 2, q = rem % 2;
+            k = 4 * t + 2 * j + q;
+        }
+        double a = 0.0;
+        if (k < h->nlat) {
+            const double m = (1.0 - x[k]) * (1.0 + x[k]);        // 1 - x^2 without the cancellation near the pole
+            if (!(m > 0.0)) return fail(EBM_ERR_ARG, "ebm_zonal_diffusion: needs |x| < 1 at every cell centre (the zonal coefficient is D/(1-x^2))");
+            a = theta * h->p.D / (m * (dl * dl));
+        }
+        const double B = 1.0 + 2.0 * a;
+        double cp_prev = 0.0, ep_prev = 0.0, gW = 0.0, f = -a, cp = 0.0, ep = 0.0;
+        for (int l = 0; l <= n - 2; ++l) {
+            const double m = 1.0 / (l == 0 ? B : B - a * cp_prev);
+            cp = a * m;
+            ep = l == 0 ? cp : a * ep_prev * m;
+            zM[(size_t)l * P + p] = m;
+            zE[(size_t)l * P + p] = ep;
+            if (l <= n - 3) {
+                gW += f * ep;
+                f = -a * ep;            // f_{l+1} = f_l cp_l = -a ep_l
+            }
+            cp_prev = cp;
+            ep_prev = ep;
+        }
+        za[p] = a;
+        zW[p] = 1.0 / (B + gW + (f - a) * (cp + ep));       // f = f_{n-2}, cp / ep = those of row n-2
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->ztab) (void)hipFree(h->ztab);
+    h->ztab = nullptr;
+    h->nlon = 0;
+    HIPCHK(hipMalloc(&h->ztab, sizeof(double) * tab.size()));
+    HIPCHK(hipMemcpy(h->ztab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+    h->nlon = nlon;
+    return EBM_OK;
+}
+hipError_t zonal_sweep(ebm_ctx *h, const double *T, double *outZ, double *outU) {
+    const size_t nP = (size_t)h->nlon * (size_t)h->pitch;
+    return ebm::launch_zonal_sweep(T, outZ, outU, h->ztab, h->ztab + nP, h->ztab + 2 * nP, h->ztab + 2 * nP + h->pitch,
+                                   h->nlon, h->ncol / h->nlon, (int)h->pitch, h->p.cw / h->dt, h->stream);
 }
 
 ebm::StepArgs base_args(const ebm_ctx *h) {
@@ -718,6 +779,7 @@ int ebm_create_ex(ebm_handle_t *out, int model, int grid, int nlat, int ncol, co
     }
     h->pitch = (long long)cfg.threads * cfg.cells;     // >= nlat; padding cells stay zero
     fill_params(h->p, params, dt);
+    h->xhost.assign(x, x + nlat);
     int rc = build_tables(h, x);
     if (rc) { ebm_destroy(h); return rc; }
     h->fstride = (long long)ncol * h->pitch;
@@ -758,7 +820,7 @@ int ebm_destroy(ebm_handle_t h) {
         h->copier->shutdown();
         delete h->copier;
     }
-    for (double *b : {h->scratch, h->ig_sums, h->ig_mean, h->ig_snap, h->ig_stage, h->ig_hm})
+    for (double *b : {h->scratch, h->ig_sums, h->ig_mean, h->ig_snap, h->ig_stage, h->ig_hm, h->ztab})
         if (b) (void)hipFree(b);
     if (h->geom) (void)hipFree(h->geom);
     if (h->state) (void)hipFree(h->state);
@@ -922,6 +984,38 @@ int ebm_diffusion(ebm_handle_t h, const double *temp, const double *base, double
                              sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("ebm_diffusion: ") + hipGetErrorString(e));
+    return EBM_OK;
+}
+
+int ebm_zonal_diffusion(ebm_handle_t h, int nlon, const double *temp, double *out_U, double *out_Z) {
+    if (!h || !temp || (!out_U && !out_Z)) return fail(EBM_ERR_ARG, "ebm_zonal_diffusion: null argument");
+    if (h->model != EBM_MODEL_MIZ) return fail(EBM_ERR_ARG, "ebm_zonal_diffusion: needs a MIZ handle (cw and D are MIZ parameters of this operator)");
+    if (nlon < 3) return fail(EBM_ERR_ARG, "ebm_zonal_diffusion: needs nlon >= 3 (longitudes per member)");
+    if (h->ncol % nlon) return fail(EBM_ERR_ARG, "ebm_zonal_diffusion: the handle's column count must be a multiple of nlon");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = build_zonal_tables(h, nlon);
+    if (rc) return rc;
+    const size_t npitch = (size_t)h->ncol * h->pitch;
+    if (!h->scratch) {                                   // temp | U | Z, [ncol][pitch] each: kept until ebm_destroy
+        HIPCHK(hipMalloc(&h->scratch, sizeof(double) * npitch * 3));
+        HIPCHK(hipMemsetAsync(h->scratch, 0, sizeof(double) * npitch * 3, h->stream));       // padding cells stay zero
+    }
+    double *buf = h->scratch;
+    hipError_t e = hipMemsetAsync(buf, 0, sizeof(double) * npitch, h->stream);            // (an earlier call left it permuted)
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(buf, sizeof(double) * h->pitch, temp, sizeof(double) * h->nlat, sizeof(double) * h->nlat,
+                             h->ncol, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = ebm::launch_split_fields(buf, 0, 1, h->ncol, h->cfg, h->stream);
+    if (e == hipSuccess) e = zonal_sweep(h, buf, buf + 2 * npitch, buf + npitch);
+    if (e == hipSuccess) e = ebm::launch_unsplit_fields(buf + npitch, (long long)npitch, 2, h->ncol, h->cfg, h->stream);
+    auto down = [&](double *dst, const double *src) {
+        return hipMemcpy2DAsync(dst, sizeof(double) * h->nlat, src, sizeof(double) * h->pitch, sizeof(double) * h->nlat,
+                                h->ncol, hipMemcpyDeviceToHost, h->stream);
+    };
+    if (e == hipSuccess && out_U) e = down(out_U, buf + npitch);
+    if (e == hipSuccess && out_Z) e = down(out_Z, buf + 2 * npitch);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("ebm_zonal_diffusion: ") + hipGetErrorString(e));
     return EBM_OK;
 }
 

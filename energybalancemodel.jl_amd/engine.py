@@ -170,6 +170,16 @@ class Engine:
         check(self.lib.ebm_diffusion(self._h, dptr(t), dptr(b), dptr(out)), "ebm_diffusion")
         return out
 
+    def zonal_diffusion(self, temp, nlon: int):
+        """The zonal partner of ``diffusion`` as a backward-Euler substep over dt (ebm_zonal_diffusion; an extension, not in
+        the reference): the columns are read as members of ``nlon`` longitudes each (column = member*nlon + longitude,
+        periodic); returns (U, Z) for ``temp`` [ncol, nlat] — the zonally diffused field and the heat-flux convergence
+        (U - temp) cw/dt = D/((1-x^2) dlambda^2) d2U/dl2."""
+        t = as_f64(temp).reshape(self.ncol, self.nlat)
+        U, Z = np.empty((self.ncol, self.nlat)), np.empty((self.ncol, self.nlat))
+        check(self.lib.ebm_zonal_diffusion(self._h, int(nlon), dptr(t), dptr(U), dptr(Z)), "ebm_zonal_diffusion")
+        return U, Z
+
     def field_device_ptr(self, name: str):
         p, pitch = C.c_void_p(), C.c_longlong()
         check(self.lib.ebm_field_device_ptr(self._h, FIELD[name], C.byref(p), C.byref(pitch)),

@@ -170,6 +170,28 @@ int ebm_get_field_device(ebm_handle_t h, int field, double *dev_out);
  * operation order.  temp, base (NULL = zeros), out: [ncol][nlat] host arrays.  MIZ handles only.
  * Synchronous. */
 int ebm_diffusion(ebm_handle_t h, const double *temp, const double *base, double *out);
+/* The ZONAL partner of the meridional operator above, as an implicit substep — an EXTENSION with no counterpart in the
+ * reference (the reference has no longitude axis; the nearest text is the meridional operator,
+ * src/infrastructure.jl:505-526), hence no parity to claim.  The columns of the handle are read as nmember = ncol / nlon
+ * latitude-longitude grids of nlon equally spaced longitudes (column = member*nlon + longitude, periodic).  The zonal part
+ * of the spherical diffusion operator, D/(1-x^2) d^2/dlambda^2, cannot be taken explicitly near the pole (1-x^2 = 6e-7 at
+ * the last of 1024 latitudes); this is its backward-Euler step over the handle's dt on a field with the water's heat
+ * capacity cw: for every member and latitude k solve the periodic tridiagonal system along the latitude circle
+ *     (1 + 2 a_k) U_l - a_k (U_{l-1} + U_{l+1}) = temp_l,    a_k = (dt/cw) D / ((1 - x_k)(1 + x_k) dlambda^2),  dlambda = 2 pi/nlon
+ * (1 - x^2 is evaluated as (1 - x)(1 + x), which does not cancel near the pole) and form the zonal heat-flux convergence
+ *     Z_l = (U_l - temp_l) cw/dt      ( = D/((1-x_k^2) dlambda^2) (U_{l-1} - 2 U_l + U_{l+1}) ).
+ * THIS TEXT IS THE DEFINITION.  The solve is free arithmetic (its result is defined by the linear system, like T0's): one
+ * lane per (member, latitude) walks the longitudes, so every access is along the contiguous latitude axis.
+ * temp, out_U, out_Z: [ncol][nlat] host arrays (either output may be NULL); nlon >= 3 must divide ncol.  MIZ-family
+ * handles.  Synchronous.
+ * Why this is an operator and not a model: coupling it to the column step by operator splitting (Z of the previous step's
+ * output temperature added to the diffusion term of both vertical fluxes) is stable on open water — there it converges
+ * to the decay of the spherical harmonics P_l^m(x) cos(m lambda) at second order — but not over thin new ice, whose surface
+ * temperature answers an enthalpy change ~60 times more strongly than water's does and without delay: zonal differences
+ * then grow ~50-fold per step until the ice has thickened (measured with the checker's restatement,
+ * tests/test_oracle_zonal.py).  A stable coupling has to put the zonal term inside the T0 balance of src/miz.jl:33-45 — a
+ * two-dimensional elliptic solve per step — which this library does not contain. */
+int ebm_zonal_diffusion(ebm_handle_t h, int nlon, const double *temp, double *out_U, double *out_Z);
 /* Device pointer of a field and its row pitch in elements (>= nlat), for zero-copy users
  * (e.g. a torch tensor view).  The pointer stays valid until ebm_destroy.  For the MIZ diagnostic fields the view
  * shows the field as of this call: steps that write them afterwards store them in a layout private to the library

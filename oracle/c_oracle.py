@@ -90,6 +90,40 @@ class COracle:
             counters, C.c_int(nthreads), C.c_int(1 if imex else 0))
         return diag, (int(counters[0]), int(counters[1]))
 
+    def zonal(self, x, par, dt, nlon, T):
+        """The zonal diffusion substep (ebm_zonal_diffusion, an extension; include/ebm_hip.h) for T[nmember*nlon, nx]:
+        returns (U, Z)."""
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        ncol, nx = T.shape
+        assert ncol % nlon == 0
+        U, Z = np.empty_like(T), np.empty_like(T)
+        self.lib.ebmo_zonal(C.c_int(nx), C.c_int(nlon), C.c_int(ncol // nlon), _ptr(np.ascontiguousarray(x, dtype=np.float64)),
+                            C.c_double(par["D"]), C.c_double(par["cw"]), C.c_double(dt), _ptr(T), _ptr(U), _ptr(Z))
+        return U, Z
+
+    def miz2d_run(self, kind, x, par, dt, nlon, ct, ft, fcol, state):
+        """CHECKER-ONLY EXPERIMENT (tests/test_oracle_zonal.py): the zonal substep coupled to the column step of the
+        implicit-diffusion extension by operator splitting.  state holds Ei, Ew, h, D, phi, T0 AND T ([nmember*nlon, nx],
+        updated in place; T is the previous step's output temperature, zeros for a start from rest).  Returns the
+        diagnostics Tw, Ti, n, E (T is in the state) and the counters."""
+        nx = len(x)
+        ncol = state["Ei"].shape[0]
+        assert ncol % nlon == 0
+        for k in ("Ei", "Ew", "h", "D", "phi", "T0", "T"):
+            assert state[k].flags.c_contiguous and state[k].shape == (ncol, nx) and state[k].dtype == np.float64, k
+        diag = {k: np.empty((ncol, nx)) for k in ("Tw", "Ti", "n", "E")}
+        ct = np.ascontiguousarray(ct, dtype=np.float64)
+        ft = np.ascontiguousarray(ft, dtype=np.float64)
+        fc = None if fcol is None else np.ascontiguousarray(fcol, dtype=np.float64)
+        counters = (C.c_longlong * 2)(0, 0)
+        self.lib.ebmo_miz2d_run(
+            C.c_int(kind), C.c_int(nx), C.c_int(nlon), C.c_int(ncol // nlon), _ptr(np.ascontiguousarray(x, dtype=np.float64)),
+            _ptr(self.par_vector(par)), C.c_double(dt), C.c_int(len(ct)), _ptr(ct), _ptr(ft), _ptr(fc),
+            *[_ptr(state[k]) for k in ("Ei", "Ew", "h", "D", "phi", "T0")],
+            *[_ptr(diag[k]) for k in ("Tw", "Ti", "n", "E")], _ptr(state["T"]),
+            counters)
+        return diag, (int(counters[0]), int(counters[1]))
+
     def T0eq(self, kind, x, par, ct, f, h, Ew, phi, T0):
         nx = len(x)
         res = np.empty(nx)

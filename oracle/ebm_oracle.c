@@ -178,7 +178,7 @@ static inline real insolation(const real *p, real x, real ct) {
 static int miz_step_col(const Geom *g, const real *p, int nx, const real *x, real dt,
                         real ct, real f, real *Ei, real *Ew, real *h, real *D,
                         real *phi, real *T0, real *Tw_o, real *Ti_o, real *n_o,
-                        real *E_o, real *T_o, Work *w, int imex) {
+                        real *E_o, real *T_o, Work *w, int imex, const real *zon) {
     const real Tm = p[P_Tm], cw = p[P_cw], A = p[P_A], B = p[P_B], ai = p[P_ai];
     const real Lf = p[P_Lf], alpha = p[P_alpha], hmin = p[P_hmin], Dmin = p[P_Dmin];
     const real Dmax = p[P_Dmax], Fb = p[P_Fb];
@@ -243,6 +243,7 @@ static int miz_step_col(const Geom *g, const real *p, int nx, const real *x, rea
             real sol_i = 0.0 + ai * S;
             real sol_w = 0.0 + (p[P_a0] - p[P_a2] * (xk * xk)) * S;
             real dif = diffusion_add(g, 0.0, w->tb, k);
+            if (zon) dif = dif + zon[k];                                   /* coupling experiment only (miz2d_run_impl) */
             real Fvi = sol_i - L + dif + Fb + f;
             real Fvw = sol_w - L + dif + Fb + f;
             w->d[k] = (ph * Fvi + (1.0 - ph) * Fvw) * dt;
@@ -264,6 +265,7 @@ static int miz_step_col(const Geom *g, const real *p, int nx, const real *x, rea
         real sol_i = 0.0 + ai * S;
         real sol_w = 0.0 + (p[P_a0] - p[P_a2] * (xk * xk)) * S;
         real dif = diffusion_add(g, 0.0, w->tb, k);
+        if (zon) dif = dif + zon[k];
         if (imex) dif = dif + w->g[k];
         real Fvi = sol_i - L + dif + Fb + f;
         real Fvw = sol_w - L + dif + Fb + f;
@@ -347,7 +349,7 @@ static int miz_run_impl(int kind, int nx, int ncol, const real *x, const real *p
             for (int s = 0; s < nsteps; ++s) {
                 real f = fcol ? ft[s] + fcol[c] : ft[s];
                 int r = miz_step_col(&g, par, nx, x, dt, ct[s], f, Ei + o, Ew + o, h + o, D + o,
-                                     phi + o, T0 + o, Tw + o, Ti + o, n + o, E + o, T + o, &w, imex);
+                                     phi + o, T0 + o, Tw + o, Ti + o, n + o, E + o, T + o, &w, imex, NULL);
                 solves += r < 0 ? -r : r;
                 fails += r < 0;
             }
@@ -357,6 +359,78 @@ static int miz_run_impl(int kind, int nx, int ncol, const real *x, const real *p
     geom_free(&g);
     if (counters) { counters[0] += solves; counters[1] += fails; }
     (void)nthreads;
+    return 0;
+}
+
+/* ---- EXTENSION, not in the reference: the zonal diffusion substep (ebm_zonal_diffusion, defined in include/ebm_hip.h) ----
+ * ncol = nmember*nlon columns, column = member*nlon + longitude, periodic in longitude.  For every member and latitude k:
+ *     (1 + 2 a_k) U_l - a_k (U_{l-1} + U_{l+1}) = T_l,   a_k = (dt/cw) D / ((1 - x_k)(1 + x_k) dlambda^2),   dlambda = 2 pi / nlon
+ *     Z_l = (U_l - T_l) cw/dt
+ * The checker's restatement solves the periodic system by Thomas + Sherman-Morrison (two solves with the matrix whose
+ * corners are folded into the first and last diagonal entries), a different algorithm from the kernel's. */
+static void zonal_impl(int nx, int nlon, int nmember, const real *x, real D, real cw, real dt, const real *T, real *U,
+                       real *Z) {
+    const real dl = 2.0 * M_PI / nlon, theta = dt / cw;
+    real *a = malloc(sizeof(real) * (size_t)nlon * 8);
+    real *sub = a, *dia = a + nlon, *sup = a + 2 * nlon, *rhs = a + 3 * nlon, *cp = a + 4 * nlon, *dp = a + 5 * nlon,
+         *y = a + 6 * nlon, *q = a + 7 * nlon;
+    for (int m = 0; m < nmember; ++m)
+        for (int k = 0; k < nx; ++k) {
+            const real ak = theta * D / (((1.0 - x[k]) * (1.0 + x[k])) * (dl * dl));
+            const real B = 1.0 + 2.0 * ak, gam = -B;
+            for (int l = 0; l < nlon; ++l) {
+                sub[l] = -ak; sup[l] = -ak; dia[l] = B;
+                rhs[l] = T[((size_t)m * nlon + l) * nx + k];
+            }
+            dia[0] = B - gam;
+            dia[nlon - 1] = B - (ak * ak) / gam;
+            thomas(nlon, sub, dia, sup, rhs, cp, dp, y);
+            for (int l = 0; l < nlon; ++l) rhs[l] = 0.0;
+            rhs[0] = gam;
+            rhs[nlon - 1] = -ak;
+            thomas(nlon, sub, dia, sup, rhs, cp, dp, q);
+            /* v = (1, 0, ..., 0, -a/gam) */
+            const real fact = (y[0] + (-ak / gam) * y[nlon - 1]) / (1.0 + q[0] + (-ak / gam) * q[nlon - 1]);
+            for (int l = 0; l < nlon; ++l) {
+                const size_t o = ((size_t)m * nlon + l) * nx + k;
+                const real u = y[l] - fact * q[l];
+                if (U) U[o] = u;
+                if (Z) Z[o] = (u - T[o]) * (cw / dt);
+            }
+        }
+    free(a);
+}
+
+/* CHECKER-ONLY EXPERIMENT (tests/test_oracle_zonal.py; nothing in the library corresponds to it): the zonal substep
+ * coupled to the column step by operator splitting, on nmember grids of nlon longitudes — per step the zonal substep on
+ * the T the previous step left (T is input AND output), then the column step of the implicit-diffusion extension with Z
+ * added to the diffusion term of both vertical fluxes.  Converges on open water, unstable over thin new ice: the
+ * measurement behind the header's statement of why the library ships the operator and not such a model. */
+static int miz2d_run_impl(int kind, int nx, int nlon, int nmember, const real *x, const real *par, real dt, int nsteps,
+                          const real *ct, const real *ft, const real *fcol, real *Ei, real *Ew, real *h, real *D,
+                          real *phi, real *T0, real *Tw, real *Ti, real *n, real *E, real *T, long long *counters) {
+    Geom g;
+    geom_init(&g, kind, nx, x, par[P_D]);
+    const int ncol = nlon * nmember;
+    real *zon = malloc(sizeof(real) * (size_t)ncol * nx);
+    Work w;
+    work_init(&w, nx);
+    long long solves = 0, fails = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        zonal_impl(nx, nlon, nmember, x, par[P_D], par[P_cw], dt, T, NULL, zon);
+        for (int c = 0; c < ncol; ++c) {
+            size_t o = (size_t)c * nx;
+            real f = fcol ? ft[s] + fcol[c] : ft[s];
+            int r = miz_step_col(&g, par, nx, x, dt, ct[s], f, Ei + o, Ew + o, h + o, D + o, phi + o, T0 + o, Tw + o,
+                                 Ti + o, n + o, E + o, T + o, &w, 1, zon + o);
+            solves += r < 0 ? -r : r;
+            fails += r < 0;
+        }
+    }
+    work_free(&w);
+    free(zon);
+    geom_free(&g);
+    if (counters) { counters[0] += solves; counters[1] += fails; }
     return 0;
 }
 
@@ -517,6 +591,44 @@ int EBMO(miz_run)(int kind, int nx, int ncol, const double *x, const double *par
     int rc = miz_run_impl(kind, nx, ncol, RARG(x), RARG(par), dt, nsteps, RARG(ct), RARG(ft), RARG(fcol),
                           RARG(Ei), RARG(Ew), RARG(h), RARG(D), RARG(phi), RARG(T0), RARG(Tw), RARG(Ti),
                           RARG(n), RARG(E), RARG(T), counters, nthreads, imex);
+    JUST_FREE(x); JUST_FREE(par); JUST_FREE(ct); JUST_FREE(ft); JUST_FREE(fcol);
+    NARROW_FREE(Ei, N); NARROW_FREE(Ew, N); NARROW_FREE(h, N); NARROW_FREE(D, N); NARROW_FREE(phi, N);
+    NARROW_FREE(T0, N); NARROW_FREE(Tw, N); NARROW_FREE(Ti, N); NARROW_FREE(n, N); NARROW_FREE(E, N);
+    NARROW_FREE(T, N);
+    return rc;
+}
+
+/* the zonal diffusion substep (ebm_zonal_diffusion): U and/or Z (either may be NULL), [nmember*nlon][nx] */
+void EBMO(zonal)(int nx, int nlon, int nmember, const double *x, double D, double cw, double dt, const double *T,
+                 double *U, double *Z) {
+    const size_t N = (size_t)nlon * nmember * nx;
+    (void)N;
+    WIDEN(x, nx); WIDEN(T, N);
+#ifdef EBMO_LONG
+    real *U_r = U ? malloc(sizeof(real) * N) : NULL, *Z_r = Z ? malloc(sizeof(real) * N) : NULL;
+#endif
+    zonal_impl(nx, nlon, nmember, RARG(x), D, cw, dt, RARG(T), RARG(U), RARG(Z));
+#ifdef EBMO_LONG
+    if (U) { narrow(U, U_r, N); free(U_r); }
+    if (Z) { narrow(Z, Z_r, N); free(Z_r); }
+#endif
+    JUST_FREE(x); JUST_FREE(T);
+}
+
+/* the coupling experiment: T is the previous step's output temperature on entry and the last step's on exit */
+int EBMO(miz2d_run)(int kind, int nx, int nlon, int nmember, const double *x, const double *par, double dt,
+                    int nsteps, const double *ct, const double *ft, const double *fcol,
+                    double *Ei, double *Ew, double *h, double *D, double *phi, double *T0,
+                    double *Tw, double *Ti, double *n, double *E, double *T, long long *counters) {
+    const int ncol = nlon * nmember;
+    const size_t N = (size_t)ncol * nx;
+    (void)N;
+    WIDEN(x, nx); WIDEN(par, P_COUNT); WIDEN(ct, nsteps); WIDEN(ft, nsteps); WIDEN(fcol, ncol);
+    WIDEN(Ei, N); WIDEN(Ew, N); WIDEN(h, N); WIDEN(D, N); WIDEN(phi, N); WIDEN(T0, N);
+    WIDEN(Tw, N); WIDEN(Ti, N); WIDEN(n, N); WIDEN(E, N); WIDEN(T, N);
+    int rc = miz2d_run_impl(kind, nx, nlon, nmember, RARG(x), RARG(par), dt, nsteps, RARG(ct), RARG(ft), RARG(fcol),
+                            RARG(Ei), RARG(Ew), RARG(h), RARG(D), RARG(phi), RARG(T0), RARG(Tw), RARG(Ti),
+                            RARG(n), RARG(E), RARG(T), counters);
     JUST_FREE(x); JUST_FREE(par); JUST_FREE(ct); JUST_FREE(ft); JUST_FREE(fcol);
     NARROW_FREE(Ei, N); NARROW_FREE(Ew, N); NARROW_FREE(h, N); NARROW_FREE(D, N); NARROW_FREE(phi, N);
     NARROW_FREE(T0, N); NARROW_FREE(Tw, N); NARROW_FREE(Ti, N); NARROW_FREE(n, N); NARROW_FREE(E, N);

@@ -447,12 +447,38 @@ def implicit_diffusion_correction(dE, dt, geom, par):
     return (thomas(a, b, c, dE) - dE) / dt
 
 
-def step_miz(ct, f, vars, T0_warm, x, dt, geom, par, imex=False):
+def zonal_substep(T, x, dt, nlon, par):
+    """EXTENSION, not in the reference (the zonal half) — "parity unpinned" by construction.  Defined in
+    include/ebm_hip.h (ebm_zonal_diffusion); this is the checker's restatement, the C oracle restates it with a different
+    algorithm (Thomas + Sherman-Morrison), the HIP kernel uses a third (periodic Thomas carrying the last unknown).
+
+    ``T`` is [nmember*nlon, nx] (column = member*nlon + longitude, periodic in longitude).  Per member and latitude k the
+    periodic tridiagonal system
+        (1 + 2 a_k) U_l - a_k (U_{l-1} + U_{l+1}) = T_l,     a_k = (dt/cw) D / ((1 - x_k)(1 + x_k) dlambda^2),  dlambda = 2 pi / nlon
+    is circulant: its eigenvectors are the discrete Fourier modes exp(2 pi i m l / nlon) with eigenvalues
+    1 + a_k (2 - 2 cos(2 pi m / nlon)) — solved here exactly that way (real FFT along the longitude axis).
+    Returns (U, Z) with Z = (U - T) cw/dt, the backward-Euler zonal heat-flux convergence D/((1-x^2) dlambda^2) d2U."""
+    T = np.asarray(T, dtype=np.float64)
+    ncol, nx = T.shape
+    assert ncol % nlon == 0 and nlon >= 3
+    dl = 2.0 * math.pi / nlon
+    a = (dt / par["cw"]) * par["D"] / (((1.0 - x) * (1.0 + x)) * (dl * dl))            # [nx]
+    lam = 2.0 - 2.0 * np.cos(2.0 * math.pi * np.arange(nlon // 2 + 1) / nlon)          # [nlon//2+1]
+    Tm = T.reshape(ncol // nlon, nlon, nx)
+    U = np.fft.irfft(np.fft.rfft(Tm, axis=1) / (1.0 + lam[None, :, None] * a[None, None, :]), n=nlon, axis=1)
+    U = U.reshape(ncol, nx)
+    return U, (U - T) * (par["cw"] / dt)
+
+
+def step_miz(ct, f, vars, T0_warm, x, dt, geom, par, imex=False, zon=None):
     """One MIZ step, src/miz.jl:150-196.
 
     ``vars`` holds Ei, Ew, h, D, phi (1-D arrays).  Returns (new vars dict with all 10
     variables, new warm start T0, n_solves, converged).  ``ct`` = cos(2.0*pi*t).
-    ``imex=True``: the extension of implicit_diffusion_correction (NOT the reference's scheme)."""
+    ``imex=True``: the extension of implicit_diffusion_correction (NOT the reference's scheme);
+    ``zon``: with it, a zonal term Z (zonal_substep of the previous step's output T) added to the diffusion term of both
+    vertical fluxes before the implicit solve — the operator-split COUPLING EXPERIMENT of tests/test_oracle_zonal.py, which
+    is how the instability over thin ice was found; it exists only in the checker, the library ships the operator alone."""
     Ei, Ew, h, D, phi = (vars[k] for k in ("Ei", "Ew", "h", "D", "phi"))
     with np.errstate(all="ignore"):
         Tw = water_temp(Ew, phi, par)
@@ -461,11 +487,21 @@ def step_miz(ct, f, vars, T0_warm, x, dt, geom, par, imex=False):
         n = num(D, phi, par)
         Fvi = vert_flux(x, ct, True, Ti, Tw, phi, f, geom, par)
         Fvw = vert_flux(x, ct, False, Ti, Tw, phi, f, geom, par)
+        if zon is not None:
+            assert imex, "the zonal term belongs to the implicit-diffusion extension"
+            tb = Tbar(Ti, Tw, phi)                               # vert_flux with dif + Z in place of dif
+            L = par["A"] + par["B"] * (tb - par["Tm"])
+            dif0 = geom.add(np.zeros_like(x), tb) + zon
+            Fvi = solar_add(np.zeros_like(x), x, ct, True, par) - L + dif0 + par["Fb"] + f
+            Fvw = solar_add(np.zeros_like(x), x, ct, False, par) - L + dif0 + par["Fb"] + f
         if imex:
             corr = implicit_diffusion_correction((phi * Fvi + (1.0 - phi) * Fvw) * dt, dt, geom, par)
             tb = Tbar(Ti, Tw, phi)                               # vert_flux with dif + corr in place of dif
             L = par["A"] + par["B"] * (tb - par["Tm"])
-            dif = geom.add(np.zeros_like(x), tb) + corr
+            dif = geom.add(np.zeros_like(x), tb)
+            if zon is not None:
+                dif = dif + zon
+            dif = dif + corr
             Fvi = solar_add(np.zeros_like(x), x, ct, True, par) - L + dif + par["Fb"] + f
             Fvw = solar_add(np.zeros_like(x), x, ct, False, par) - L + dif + par["Fb"] + f
         Flat = lat_flux(h, D, Tw, phi, par)

@@ -269,7 +269,7 @@ def test_diagnostic_fields_read_back_in_the_natural_layout(pkg, nlat, ncol, nt):
 
 @pytest.mark.parametrize("nlat,ncol", [(180, 1), (181, 7), (1024, 4100), (4096, 1100), (2, 3)])
 def test_host_transfers_through_the_pinned_ring(pkg, nlat, ncol):
-    """ebm_set_field / ebm_get_field move fields through a pinned staging ring in pieces of 4 MiB, host threads on one
+    """ebm_set_field / ebm_get_field move fields through a pinned staging ring in pieces of 16 MiB, host threads on one
     side and the DMA engine on the other: whatever the shape (rows shorter than the pitch, fields of several pieces,
     a piece boundary inside the field), what comes back is what went in, and padding cells stay zero."""
     rng = np.random.default_rng(nlat * 1000 + ncol)
