@@ -76,6 +76,7 @@ struct StepArgs {
     unsigned long long *counters;    // 64 shards x {solves, cap hits} (MIZ)
     unsigned short *amask;           // MIZ warm start as an active set: [ncol][threads], bit i <=> T0 < Tm in cell i of the thread
     int pitch, nlat, ncol;
+    int col0;                        // first column of this launch (workgroup b steps column col0 + b): launch chains
     double ct, ct_next, ft;          // cos(2 pi t) [MIZ / classic column i], classic column i+1, forcing
     double tyear;                    // model time of the step in years (st.T[tinx]), for the schedules
     const StepSched *sched;          // if non-null, ct/ct_next/ft come from sched[slot] instead (graph replay)
@@ -118,8 +119,10 @@ KernelFn miz_step_kernels_identity(int cells, int mode, int threads);
 KernelFn miz_step_kernels_nonuniform(int cells, int mode, int threads);
 KernelFn miz_step_kernels_imex(int grid_kind, int mode, int threads);
 
-hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, bool imex, hipStream_t s);
-hipError_t launch_classic_step(const StepArgs &a, int mode, const LaunchCfg &cfg, hipStream_t s);
+// `count` workgroups, stepping columns first ... first + count - 1
+hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, bool imex, int first, int count,
+                           hipStream_t s);
+hipError_t launch_classic_step(const StepArgs &a, int mode, const LaunchCfg &cfg, int first, int count, hipStream_t s);
 // rcp_dt / rcp_cdn of the device-resident parameter block (see Params)
 hipError_t launch_derive_params(Params *p_dev, hipStream_t s);
 // active set from the T0 field (after ebm_set_field(T0))

@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(TT, 4) miz_step_kernel(const StepArgs a) {
     constexpr bool MAYDIAG = OUT != OUT_STATE;            // diagnostic stores compiled in
     extern __shared__ double smem[];
     constexpr int T = TT;
-    const int t = threadIdx.x, col = blockIdx.x;
+    const int t = threadIdx.x, col = a.col0 + (int)blockIdx.x;
     const int nlat = a.nlat;
     const unsigned k0 = (unsigned)t * C;
     double *P0 = smem, *P1 = smem + 3 * T;
@@ -985,7 +985,7 @@ __global__ void __launch_bounds__(TT) miz_fused_kernel(const StepArgs a) {
     static_assert(C == 2 || C == 4, "cells per thread");
     constexpr int T = TT;
     extern __shared__ double smem[];
-    const int t = threadIdx.x, col = blockIdx.x;
+    const int t = threadIdx.x, col = a.col0 + (int)blockIdx.x;
     const int nlat = a.nlat;
     const unsigned k0 = (unsigned)t * C;
     double *P0 = smem, *P1 = smem + 3 * T;
@@ -1124,7 +1124,7 @@ __global__ void __launch_bounds__(1024) classic_step_kernel(const StepArgs a) {
     static_assert(C == 2 || C == 4, "cells per thread");
     constexpr bool LOOP = MODE == OUT_LOOP;
     extern __shared__ double smem[];
-    const int T = blockDim.x, t = threadIdx.x, col = blockIdx.x;
+    const int T = blockDim.x, t = threadIdx.x, col = a.col0 + (int)blockIdx.x;
     const int nlat = a.nlat;
     const unsigned k0 = (unsigned)t * C;
     double *P0 = smem, *P1 = smem + 3 * T;
@@ -1593,17 +1593,22 @@ hipError_t prepare_kernels(const LaunchCfg &cfg) {
     return hipSuccess;
 }
 
-hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, bool imex, hipStream_t s) {
+hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, bool imex, int first, int count,
+                           hipStream_t s) {
     KernelFn fn = miz_kernel(cfg.cells, grid_kind, mode, cfg.threads, imex);
-    if (!fn) return hipErrorInvalidValue;
-    fn<<<dim3(a.ncol), dim3(cfg.threads), miz_lds_bytes(cfg, mode), s>>>(a);
+    if (!fn || first < 0 || count < 1 || first + count > a.ncol) return hipErrorInvalidValue;
+    StepArgs b = a;
+    b.col0 = first;
+    fn<<<dim3(count), dim3(cfg.threads), miz_lds_bytes(cfg, mode), s>>>(b);
     return hipGetLastError();
 }
 
-hipError_t launch_classic_step(const StepArgs &a, int mode, const LaunchCfg &cfg, hipStream_t s) {
+hipError_t launch_classic_step(const StepArgs &a, int mode, const LaunchCfg &cfg, int first, int count, hipStream_t s) {
     KernelFn fn = classic_kernel(cfg.cells, mode);
-    if (!fn) return hipErrorInvalidValue;
-    fn<<<dim3(a.ncol), dim3(cfg.threads), sizeof(double) * 6 * (size_t)cfg.threads, s>>>(a);
+    if (!fn || first < 0 || count < 1 || first + count > a.ncol) return hipErrorInvalidValue;
+    StepArgs b = a;
+    b.col0 = first;
+    fn<<<dim3(count), dim3(cfg.threads), sizeof(double) * 6 * (size_t)cfg.threads, s>>>(b);
     return hipGetLastError();
 }
 

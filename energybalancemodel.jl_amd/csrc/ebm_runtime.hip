@@ -313,8 +313,18 @@ struct ebm_ctx {
     unsigned long long *counters = nullptr;        // device, kCounterShards x 2
     unsigned short *amask = nullptr;               // MIZ warm-start active set, ncol x threads
     long long n_steps = 0, n_launches = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                  // THE stream of the handle: everything is ordered on it (see main_stream)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Two chains of step launches.  Long meridians leave room for ONE workgroup per CU, so within a launch nothing runs under
+    // a workgroup's load, solve and store phases, and a launch cannot start before the slowest workgroup of the previous one
+    // has ended.  Columns are independent: the first half of them is stepped on `stream`, the second on `stream2`, each half
+    // its own chain of launches; the chains drift apart and fill each other's gaps (measured on 4096 x 2048: 0.1656 ->
+    // 0.1594 ms per step, tests/tools/ab_two_handles.py).  `forked` = the chains are running apart; any other use of the
+    // handle's stream joins them first (main_stream).
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int split_col = 0;                             // 0: one chain; else the first column of the second chain
+    bool forked = false;
     // Validity of the fields that only some steps write (diagnostics, the fp64 T0): `epoch` counts every change
     // of the prognostic state (steps taken, prognostic fields overwritten), `state_step` is the global index of
     // the last step taken (-1: none); a field is current iff written_epoch[f] == epoch.
@@ -336,6 +346,17 @@ struct ebm_ctx {
 };
 
 namespace {
+
+// The handle's stream for everything that is not a step launch.  If the two chains of step launches are running apart
+// (ebm_ctx::forked), the second one is joined first: whatever is enqueued next is ordered after all steps of all columns.
+hipStream_t main_stream(ebm_ctx *h) {
+    if (h->forked) {
+        (void)hipEventRecord(h->ev_join, h->stream2);
+        (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);
+        h->forked = false;
+    }
+    return h->stream;
+}
 
 // slab slot of a public field id for this model, -1 if the model does not have it
 int slot_of(int model, int f) {
@@ -526,7 +547,7 @@ int build_zonal_tables(ebm_ctx *h, int nlon) {
         za[p] = a;
         zW[p] = 1.0 / (B + gW + (f - a) * (cp + ep));       // f = f_{n-2}, cp / ep = those of row n-2
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(main_stream(h)));
     if (h->ztab) (void)hipFree(h->ztab);
     h->ztab = nullptr;
     h->nlon = 0;
@@ -538,7 +559,7 @@ int build_zonal_tables(ebm_ctx *h, int nlon) {
 hipError_t zonal_sweep(ebm_ctx *h, const double *T, double *outZ, double *outU) {
     const size_t nP = (size_t)h->nlon * (size_t)h->pitch;
     return ebm::launch_zonal_sweep(T, outZ, outU, h->ztab, h->ztab + nP, h->ztab + 2 * nP, h->ztab + 2 * nP + h->pitch,
-                                   h->nlon, h->ncol / h->nlon, (int)h->pitch, h->p.cw / h->dt, h->stream);
+                                   h->nlon, h->ncol / h->nlon, (int)h->pitch, h->p.cw / h->dt, main_stream(h));
 }
 
 ebm::StepArgs base_args(const ebm_ctx *h) {
@@ -555,17 +576,30 @@ ebm::StepArgs base_args(const ebm_ctx *h) {
 
 constexpr int kGraphSteps = 64;
 
+
 // mode: ebm::OutMode.  The classic kernel decides about T, h at run time (write_diag).
+hipError_t launch_columns(ebm_ctx *h, const ebm::StepArgs &a, int mode, int first, int count, hipStream_t s) {
+    return (h->model == EBM_MODEL_MIZ) ? ebm::launch_miz_step(a, h->grid, mode, h->cfg, h->imex, first, count, s)
+                                       : ebm::launch_classic_step(a, mode, h->cfg, first, count, s);
+}
 hipError_t launch_step(ebm_ctx *h, const ebm::StepArgs &a, int mode) {
-    return (h->model == EBM_MODEL_MIZ) ? ebm::launch_miz_step(a, h->grid, mode, h->cfg, h->imex, h->stream)
-                                       : ebm::launch_classic_step(a, mode, h->cfg, h->stream);
+    if (!h->split_col) return launch_columns(h, a, mode, 0, h->ncol, main_stream(h));
+    if (!h->forked) {            // the second chain starts after everything the handle's stream has been given so far
+        hipError_t e = hipEventRecord(h->ev_fork, h->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(h->stream2, h->ev_fork, 0);
+        if (e != hipSuccess) return e;
+        h->forked = true;
+    }
+    hipError_t e = launch_columns(h, a, mode, 0, h->split_col, h->stream);
+    if (e == hipSuccess) e = launch_columns(h, a, mode, h->split_col, h->ncol - h->split_col, h->stream2);
+    return e;
 }
 
 // Capture kGraphSteps step kernels (node i reads sched_dev[i]) into a graph, once per handle.
 int build_graph(ebm_ctx *h) {
     HIPCHK(hipMalloc(&h->sched_dev, sizeof(ebm::StepSched) * kGraphSteps));
     hipGraph_t graph = nullptr;
-    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    HIPCHK(hipStreamBeginCapture(main_stream(h), hipStreamCaptureModeThreadLocal));
     hipError_t e = hipSuccess;
     for (int i = 0; i < kGraphSteps && e == hipSuccess; ++i) {
         ebm::StepArgs a = base_args(h);
@@ -574,7 +608,7 @@ int build_graph(ebm_ctx *h) {
         a.write_diag = 0;
         e = launch_step(h, a, ebm::OUT_STATE);
     }
-    hipError_t e2 = hipStreamEndCapture(h->stream, &graph);
+    hipError_t e2 = hipStreamEndCapture(main_stream(h), &graph);
     if (e != hipSuccess || e2 != hipSuccess) {
         if (graph) (void)hipGraphDestroy(graph);
         return fail(EBM_ERR_HIP, std::string("graph capture: ") + hipGetErrorString(e != hipSuccess ? e : e2));
@@ -623,7 +657,7 @@ int do_step(ebm_ctx *h, double ct, double ct_next, double f, int write_diag, lon
     hipError_t e = launch_step(h, a, mode);
     if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
     h->n_steps += 1;
-    h->n_launches += 1;
+    h->n_launches += h->split_col ? 2 : 1;
     h->clock = step + 1;
     note_steps(h, 1, step, write_diag != 0);
     // the 4-cells-per-thread MIZ step kernels leave the diagnostic fields pair-split (ensure_natural undoes it)
@@ -634,7 +668,7 @@ int do_step(ebm_ctx *h, double ct, double ct_next, double f, int write_diag, lon
 // Readers of a diagnostic field get the natural layout: un-permute in place once after a step that stored them split.
 int ensure_natural(ebm_ctx *h) {
     if (!h->diag_split) return EBM_OK;
-    hipError_t e = ebm::launch_unsplit_fields(h->field[EBM_F_Tw], h->fstride, 5, h->ncol, h->cfg, h->stream);
+    hipError_t e = ebm::launch_unsplit_fields(h->field[EBM_F_Tw], h->fstride, 5, h->ncol, h->cfg, main_stream(h));
     if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("unsplit_fields: ") + hipGetErrorString(e));
     h->diag_split = false;
     return EBM_OK;
@@ -708,6 +742,7 @@ int ebm_options_default(ebm_options *opt) {
     opt->cells_per_thread = 0;
     opt->use_graph = -1;
     opt->prefetch_cols = -1;
+    opt->launch_chains = -1;
     return EBM_OK;
 }
 
@@ -733,6 +768,8 @@ int ebm_create_ex(ebm_handle_t *out, int model, int grid, int nlat, int ncol, co
         return fail(EBM_ERR_ARG, "ebm_create_ex: cells_per_thread must be 0 (default), 2 or 4");
     if (opt.use_graph < -1 || opt.use_graph > 1) return fail(EBM_ERR_ARG, "ebm_create_ex: use_graph must be -1, 0 or 1");
     if (opt.prefetch_cols < -1) return fail(EBM_ERR_ARG, "ebm_create_ex: prefetch_cols must be -1 (default), 0 or a distance");
+    if (opt.launch_chains != -1 && opt.launch_chains != 1 && opt.launch_chains != 2)
+        return fail(EBM_ERR_ARG, "ebm_create_ex: launch_chains must be -1 (default), 1 or 2");
     if (model != EBM_MODEL_MIZ && model != EBM_MODEL_CLASSIC && model != EBM_MODEL_MIZ_IMEX)
         return fail(EBM_ERR_ARG, "ebm_create: unknown model");
     const bool imex = model == EBM_MODEL_MIZ_IMEX;        // the extension is the MIZ model with one more solve per step
@@ -776,6 +813,9 @@ int ebm_create_ex(ebm_handle_t *out, int model, int grid, int nlat, int ncol, co
         const int ahead = h->num_cus * per_cu;                                // the successor on the same XCD
         // measured: -3.5 % time at one workgroup per CU, -2.5 % at two, nothing beyond
         h->prefetch = opt.prefetch_cols >= 0 ? opt.prefetch_cols : (per_cu <= 2 && ncol > ahead ? ahead : 0);
+        // two chains of launches (see ebm_ctx::stream2): on request only — the default stays one launch per step, whose
+        // duration a profiler reports as such; never with graph replay (one captured stream)
+        h->split_col = (opt.launch_chains == 2 && !h->use_graph && ncol >= 2) ? ncol / 2 : 0;
     }
     h->pitch = (long long)cfg.threads * cfg.cells;     // >= nlat; padding cells stay zero
     fill_params(h->p, params, dt);
@@ -805,6 +845,9 @@ int ebm_create_ex(ebm_handle_t *out, int model, int grid, int nlat, int ncol, co
     e = hipMalloc(&h->counters, sizeof(unsigned long long) * 2 * ebm::kCounterShards);
     if (e == hipSuccess) e = hipMemset(h->counters, 0, sizeof(unsigned long long) * 2 * ebm::kCounterShards);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess && h->split_col) e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess && h->split_col) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess && h->split_col) e = hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&h->ev0);
     if (e == hipSuccess) e = hipEventCreate(&h->ev1);
     if (e != hipSuccess) { ebm_destroy(h); return fail(EBM_ERR_HIP, std::string("ebm_create: ") + hipGetErrorString(e)); }
@@ -815,7 +858,7 @@ int ebm_create_ex(ebm_handle_t *out, int model, int grid, int nlat, int ncol, co
 int ebm_destroy(ebm_handle_t h) {
     if (!h) return EBM_OK;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream) (void)hipStreamSynchronize(main_stream(h));
     if (h->copier) {
         h->copier->shutdown();
         delete h->copier;
@@ -835,6 +878,9 @@ int ebm_destroy(ebm_handle_t h) {
     if (h->counters) (void)hipFree(h->counters);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return EBM_OK;
@@ -850,14 +896,14 @@ int ebm_set_field(ebm_handle_t h, int field, const double *host) {
         rc = ensure_natural(h);                   // the other diagnostic fields keep their values, in the natural layout
         if (rc) return rc;
     }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(main_stream(h)));
     HIPCHK(h->copier->wait_all());
     HIPCHK(h->copier->upload(h->field[field], (size_t)h->pitch, host, (size_t)h->nlat, (size_t)h->ncol));
     if (field == EBM_F_T0 && h->model == EBM_MODEL_MIZ) {
         // the stepping kernels carry the warm start as its active set: rebuild it from the new T0
-        hipError_t e = ebm::launch_mask_from_t0(base_args(h), h->ncol, h->cfg, h->stream);
+        hipError_t e = ebm::launch_mask_from_t0(base_args(h), h->ncol, h->cfg, main_stream(h));
         if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("mask_from_t0: ") + hipGetErrorString(e));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipStreamSynchronize(main_stream(h)));
     }
     if (is_diagnostic(h, field)) {                // the caller's statement of what the field holds: current as of now
         h->written_epoch[field] = h->epoch;
@@ -878,7 +924,7 @@ static int download_field(ebm_handle_t h, int field, double *host, const char *w
     }
     HostCopier *c = h->copier;
     HIPCHK(c->wait_all());
-    HIPCHK(c->order_after(h->stream));
+    HIPCHK(c->order_after(main_stream(h)));
     CopyJob j;
     j.src = h->field[field]; j.src_pitch = (size_t)h->pitch; j.row_elems = (size_t)h->nlat; j.nrows = (size_t)h->ncol; j.dst = host;
     hipError_t e = c->run(j);
@@ -925,9 +971,9 @@ int ebm_hemispheric_mean(ebm_handle_t h, int field, double *out) {
     HIPCHK(hipSetDevice(h->device));
     if (is_split_field(h, field) && (rc = ensure_natural(h))) return rc;
     hipError_t e = ebm::launch_hemispheric_mean(h->field[field], h->geom + (size_t)ebm::G_X * h->gstride, (int)h->pitch,
-                                                h->nlat, h->ncol, h->hm_dev, h->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out, h->hm_dev, sizeof(double) * (size_t)h->ncol, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                                                h->nlat, h->ncol, h->hm_dev, main_stream(h));
+    if (e == hipSuccess) e = hipMemcpyAsync(out, h->hm_dev, sizeof(double) * (size_t)h->ncol, hipMemcpyDeviceToHost, main_stream(h));
+    if (e == hipSuccess) e = hipStreamSynchronize(main_stream(h));
     if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("ebm_hemispheric_mean: ") + hipGetErrorString(e));
     return EBM_OK;
 }
@@ -940,8 +986,8 @@ int ebm_hemispheric_mean_device(ebm_handle_t h, int field, double *dev_out) {
     HIPCHK(hipSetDevice(h->device));
     if (is_split_field(h, field) && (rc = ensure_natural(h))) return rc;
     hipError_t e = ebm::launch_hemispheric_mean(h->field[field], h->geom + (size_t)ebm::G_X * h->gstride, (int)h->pitch,
-                                                h->nlat, h->ncol, dev_out, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                                                h->nlat, h->ncol, dev_out, main_stream(h));
+    if (e == hipSuccess) e = hipStreamSynchronize(main_stream(h));
     if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("ebm_hemispheric_mean_device: ") + hipGetErrorString(e));
     return EBM_OK;
 }
@@ -954,8 +1000,8 @@ int ebm_get_field_device(ebm_handle_t h, int field, double *dev_out) {
     HIPCHK(hipSetDevice(h->device));
     if (is_split_field(h, field) && (rc = ensure_natural(h))) return rc;
     HIPCHK(hipMemcpy2DAsync(dev_out, sizeof(double) * h->nlat, h->field[field], sizeof(double) * h->pitch,
-                            sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToDevice, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+                            sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToDevice, main_stream(h)));
+    HIPCHK(hipStreamSynchronize(main_stream(h)));
     return EBM_OK;
 }
 
@@ -967,22 +1013,22 @@ int ebm_diffusion(ebm_handle_t h, const double *temp, const double *base, double
     const size_t npitch = (size_t)h->ncol * h->pitch;
     if (!h->scratch) {                                   // temp | base | out, [ncol][pitch] each: kept until ebm_destroy
         HIPCHK(hipMalloc(&h->scratch, sizeof(double) * npitch * 3));
-        HIPCHK(hipMemsetAsync(h->scratch, 0, sizeof(double) * npitch * 3, h->stream));       // padding cells stay zero
+        HIPCHK(hipMemsetAsync(h->scratch, 0, sizeof(double) * npitch * 3, main_stream(h)));       // padding cells stay zero
     }
     double *buf = h->scratch;
     auto up = [&](double *dst, const double *src) {
         return hipMemcpy2DAsync(dst, sizeof(double) * h->pitch, src, sizeof(double) * h->nlat, sizeof(double) * h->nlat,
-                                h->ncol, hipMemcpyHostToDevice, h->stream);
+                                h->ncol, hipMemcpyHostToDevice, main_stream(h));
     };
     hipError_t e = up(buf, temp);
     if (e == hipSuccess && base) e = up(buf + npitch, base);
     if (e == hipSuccess)
         e = ebm::launch_diffusion(buf, base ? buf + npitch : nullptr, buf + 2 * npitch, h->geom, h->gstride, h->p_dev,
-                                  h->grid, (int)h->pitch, h->nlat, h->ncol, h->stream);
+                                  h->grid, (int)h->pitch, h->nlat, h->ncol, main_stream(h));
     if (e == hipSuccess)
         e = hipMemcpy2DAsync(out, sizeof(double) * h->nlat, buf + 2 * npitch, sizeof(double) * h->pitch,
-                             sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+                             sizeof(double) * h->nlat, h->ncol, hipMemcpyDeviceToHost, main_stream(h));
+    if (e == hipSuccess) e = hipStreamSynchronize(main_stream(h));
     if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("ebm_diffusion: ") + hipGetErrorString(e));
     return EBM_OK;
 }
@@ -998,23 +1044,23 @@ int ebm_zonal_diffusion(ebm_handle_t h, int nlon, const double *temp, double *ou
     const size_t npitch = (size_t)h->ncol * h->pitch;
     if (!h->scratch) {                                   // temp | U | Z, [ncol][pitch] each: kept until ebm_destroy
         HIPCHK(hipMalloc(&h->scratch, sizeof(double) * npitch * 3));
-        HIPCHK(hipMemsetAsync(h->scratch, 0, sizeof(double) * npitch * 3, h->stream));       // padding cells stay zero
+        HIPCHK(hipMemsetAsync(h->scratch, 0, sizeof(double) * npitch * 3, main_stream(h)));       // padding cells stay zero
     }
     double *buf = h->scratch;
-    hipError_t e = hipMemsetAsync(buf, 0, sizeof(double) * npitch, h->stream);            // (an earlier call left it permuted)
+    hipError_t e = hipMemsetAsync(buf, 0, sizeof(double) * npitch, main_stream(h));            // (an earlier call left it permuted)
     if (e == hipSuccess)
         e = hipMemcpy2DAsync(buf, sizeof(double) * h->pitch, temp, sizeof(double) * h->nlat, sizeof(double) * h->nlat,
-                             h->ncol, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = ebm::launch_split_fields(buf, 0, 1, h->ncol, h->cfg, h->stream);
+                             h->ncol, hipMemcpyHostToDevice, main_stream(h));
+    if (e == hipSuccess) e = ebm::launch_split_fields(buf, 0, 1, h->ncol, h->cfg, main_stream(h));
     if (e == hipSuccess) e = zonal_sweep(h, buf, buf + 2 * npitch, buf + npitch);
-    if (e == hipSuccess) e = ebm::launch_unsplit_fields(buf + npitch, (long long)npitch, 2, h->ncol, h->cfg, h->stream);
+    if (e == hipSuccess) e = ebm::launch_unsplit_fields(buf + npitch, (long long)npitch, 2, h->ncol, h->cfg, main_stream(h));
     auto down = [&](double *dst, const double *src) {
         return hipMemcpy2DAsync(dst, sizeof(double) * h->nlat, src, sizeof(double) * h->pitch, sizeof(double) * h->nlat,
-                                h->ncol, hipMemcpyDeviceToHost, h->stream);
+                                h->ncol, hipMemcpyDeviceToHost, main_stream(h));
     };
     if (e == hipSuccess && out_U) e = down(out_U, buf + npitch);
     if (e == hipSuccess && out_Z) e = down(out_Z, buf + 2 * npitch);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(main_stream(h));
     if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("ebm_zonal_diffusion: ") + hipGetErrorString(e));
     return EBM_OK;
 }
@@ -1027,7 +1073,7 @@ int ebm_field_device_ptr(ebm_handle_t h, int field, double **dptr, long long *pi
     if (is_split_field(h, field)) {                      // the view is of the natural layout as of this call
         HIPCHK(hipSetDevice(h->device));
         if ((rc = ensure_natural(h))) return rc;
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipStreamSynchronize(main_stream(h)));
     }
     *dptr = h->field[field];
     if (pitch) *pitch = h->pitch;
@@ -1037,7 +1083,7 @@ int ebm_field_device_ptr(ebm_handle_t h, int field, double **dptr, long long *pi
 int ebm_set_column_forcing(ebm_handle_t h, const double *fcol) {
     if (!h) return fail(EBM_ERR_ARG, "ebm_set_column_forcing: null handle");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(main_stream(h)));
     if (!fcol) {
         if (h->fcol) { HIPCHK(hipFree(h->fcol)); invalidate_graph(h); }
         h->fcol = nullptr;
@@ -1051,7 +1097,7 @@ int ebm_set_column_forcing(ebm_handle_t h, const double *fcol) {
 int ebm_set_column_schedule(ebm_handle_t h, const double *sched) {
     if (!h) return fail(EBM_ERR_ARG, "ebm_set_column_schedule: null handle");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(main_stream(h)));
     const size_t nb = sizeof(double) * ebm::kSchedWords * (size_t)h->ncol;
     if (!sched) {
         if (h->fsched) { HIPCHK(hipFree(h->fsched)); invalidate_graph(h); }
@@ -1112,8 +1158,8 @@ int ebm_run(ebm_handle_t h, long long first_step, int nsteps, const double *f_st
             }
             // pageable source: the copy is staged before the call returns, so `sched` can be refilled
             HIPCHK(hipMemcpyAsync(h->sched_dev, sched.data(), sizeof(ebm::StepSched) * kGraphSteps,
-                                  hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
+                                  hipMemcpyHostToDevice, main_stream(h)));
+            HIPCHK(hipGraphLaunch(h->graph_exec, main_stream(h)));
             h->n_steps += kGraphSteps;
             h->n_launches += kGraphSteps;
             h->clock = first_step + s + kGraphSteps;
@@ -1152,7 +1198,7 @@ int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double
             sched[i].tyear = year_time(h, first_step + s0 + i);
         }
         // the launches of the previous batch still read the table: drain them before it is refilled
-        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipStreamSynchronize(main_stream(h)));
         HIPCHK(hipMemcpy(h->fused_sched, sched.data(), sizeof(ebm::StepSched) * (size_t)n, hipMemcpyHostToDevice));
         for (int i = 0; i < n; i += steps_per_launch) {
             ebm::StepArgs a = base_args(h);
@@ -1163,7 +1209,7 @@ int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double
             a.write_diag = (diag_last && s0 + i + a.nfused == nsteps) ? 1 : 0;
             hipError_t e = launch_step(h, a, ebm::OUT_LOOP);
             if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
-            h->n_launches += 1;
+            h->n_launches += h->split_col ? 2 : 1;
             note_steps(h, a.nfused, first_step + s0 + i + a.nfused - 1, a.write_diag != 0);
             if (a.write_diag && h->model == EBM_MODEL_MIZ) h->diag_split = false;      // the fused kernel stores them in the natural layout
         }
@@ -1231,7 +1277,7 @@ static int integrate_impl(ebm_handle_t h, int nt, int dur, const double *f_steps
     if (want_hm) EBM_TRY(keep_buffer(&h->ig_hm, &h->ig_hm_n, (size_t)h->ncol * (size_t)nvars));
     if (want_sums) {
         EBM_TRY(keep_buffer(&h->ig_sums, &h->ig_sums_n, npitch * (size_t)nvars));
-        EBM_TRY(hipMemsetAsync(h->ig_sums, 0, sizeof(double) * npitch * (size_t)nvars, h->stream));
+        EBM_TRY(hipMemsetAsync(h->ig_sums, 0, sizeof(double) * npitch * (size_t)nvars, main_stream(h)));
         EBM_TRY(keep_buffer(&h->ig_mean, &h->ig_mean_n, npitch * (size_t)nvars));
     }
     if (want_snap) EBM_TRY(keep_buffer(&h->ig_snap, &h->ig_snap_n, npitch * (size_t)nvars));
@@ -1243,10 +1289,10 @@ static int integrate_impl(ebm_handle_t h, int nt, int dur, const double *f_steps
     auto means_to_host = [&](double *out, long long year, auto field_of) -> hipError_t {
         for (int v = 0; v < nvars; ++v) {
             hipError_t e = ebm::launch_hemispheric_mean(field_of(v), h->geom + (size_t)ebm::G_X * h->gstride, (int)h->pitch,
-                                                        h->nlat, h->ncol, hm + (size_t)v * h->ncol, h->stream);
+                                                        h->nlat, h->ncol, hm + (size_t)v * h->ncol, main_stream(h));
             if (e != hipSuccess) return e;
         }
-        hipError_t e = hipStreamSynchronize(h->stream);
+        hipError_t e = hipStreamSynchronize(main_stream(h));
         for (int v = 0; v < nvars && e == hipSuccess; ++v)
             e = hipMemcpy(out + ((size_t)v * dur + (size_t)(year - 1)) * h->ncol, hm + (size_t)v * h->ncol,
                           sizeof(double) * (size_t)h->ncol, hipMemcpyDeviceToHost);
@@ -1257,7 +1303,7 @@ static int integrate_impl(ebm_handle_t h, int nt, int dur, const double *f_steps
     save.stage_var_stride = chunk * (long long)npitch;
     // one asynchronous job per saved variable: [ncol][pitch] on the device -> packed [ncol][nlat] at dst
     auto fields_to_host = [&](double *dst_base, long long year, const double *dev_base) -> hipError_t {
-        hipError_t e = cp->order_after(h->stream);
+        hipError_t e = cp->order_after(main_stream(h));
         for (int v = 0; v < nvars && e == hipSuccess; ++v) {
             CopyJob j;
             j.src = dev_base + (size_t)v * npitch; j.src_pitch = (size_t)h->pitch; j.row_elems = (size_t)h->nlat;
@@ -1270,7 +1316,7 @@ static int integrate_impl(ebm_handle_t h, int nt, int dur, const double *f_steps
     auto season_to_host = [&](double *dst_base, long long year) -> hipError_t {
         hipError_t e = cp->wait_all();                                       // the previous snapshot has left `snap`
         for (int v = 0; v < nvars && e == hipSuccess; ++v)
-            e = hipMemcpyAsync(snap + (size_t)v * npitch, h->field[fields[v]], sizeof(double) * npitch, hipMemcpyDeviceToDevice, h->stream);
+            e = hipMemcpyAsync(snap + (size_t)v * npitch, h->field[fields[v]], sizeof(double) * npitch, hipMemcpyDeviceToDevice, main_stream(h));
         if (e == hipSuccess) e = fields_to_host(dst_base, year, snap);
         return e;
     };
@@ -1281,7 +1327,7 @@ static int integrate_impl(ebm_handle_t h, int nt, int dur, const double *f_steps
         if (!staged) return hipSuccess;
         // the half just filled goes out while the steps fill the other one — whose previous contents must have left
         hipError_t e = cp->wait_all();
-        if (e == hipSuccess) e = cp->order_after(h->stream);
+        if (e == hipSuccess) e = cp->order_after(main_stream(h));
         for (int v = 0; v < nvars && e == hipSuccess; ++v) {
             CopyJob j;      // `staged` snapshots of ncol rows each: (staged * ncol) rows of nlat doubles, pitch apart
             j.src = stage + (size_t)half * (size_t)nvars * chunk * npitch + (size_t)v * chunk * npitch;
@@ -1320,16 +1366,16 @@ static int integrate_impl(ebm_handle_t h, int nt, int dur, const double *f_steps
         } else if (ti == nt) {
             if (sums) {
                 EBM_TRY(cp->wait_all());                                     // last year's means have left `mean`
-                EBM_TRY(ebm::launch_finish_mean(mean, sums, (double)nt, h->ncol, nvars, (long long)npitch, h->cfg, h->stream));
+                EBM_TRY(ebm::launch_finish_mean(mean, sums, (double)nt, h->ncol, nvars, (long long)npitch, h->cfg, main_stream(h)));
                 if (avg) EBM_TRY(fields_to_host(avg, year, mean));
                 if (hm_avg) EBM_TRY(means_to_host(hm_avg, year, [&](int v) { return (const double *)(mean + (size_t)v * npitch); }));
             }
         }
         if (sums && ti == nt && !(ti != winter_inx && ti != summer_inx))   // year ended on a seasonal index:
-            EBM_TRY(hipMemsetAsync(sums, 0, sizeof(double) * npitch * (size_t)nvars, h->stream));  // no mean is taken, restart sums
+            EBM_TRY(hipMemsetAsync(sums, 0, sizeof(double) * npitch * (size_t)nvars, main_stream(h)));  // no mean is taken, restart sums
     }
     EBM_TRY(flush());
-    EBM_TRY(hipStreamSynchronize(h->stream));
+    EBM_TRY(hipStreamSynchronize(main_stream(h)));
     EBM_TRY(cp->wait_all());
 #undef EBM_TRY
     return EBM_OK;
@@ -1352,14 +1398,14 @@ int ebm_integrate_hemispheric(ebm_handle_t h, int nt, int dur, const double *f_s
 int ebm_sync(ebm_handle_t h) {
     if (!h) return fail(EBM_ERR_ARG, "ebm_sync: null handle");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(main_stream(h)));
     return EBM_OK;
 }
 
 int ebm_get_counters(ebm_handle_t h, long long *counters) {
     if (!h || !counters) return fail(EBM_ERR_ARG, "ebm_get_counters: null argument");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(main_stream(h)));
     unsigned long long host[2 * ebm::kCounterShards];
     HIPCHK(hipMemcpy(host, h->counters, sizeof(host), hipMemcpyDeviceToHost));
     long long solves = 0, caps = 0;
@@ -1377,7 +1423,7 @@ int ebm_get_counters(ebm_handle_t h, long long *counters) {
 int ebm_reset_counters(ebm_handle_t h) {
     if (!h) return fail(EBM_ERR_ARG, "ebm_reset_counters: null handle");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(main_stream(h)));
     HIPCHK(hipMemset(h->counters, 0, sizeof(unsigned long long) * 2 * ebm::kCounterShards));
     h->n_steps = 0;
     h->n_launches = 0;
@@ -1387,14 +1433,14 @@ int ebm_reset_counters(ebm_handle_t h) {
 int ebm_timer_start(ebm_handle_t h) {
     if (!h) return fail(EBM_ERR_ARG, "ebm_timer_start: null handle");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    HIPCHK(hipEventRecord(h->ev0, main_stream(h)));
     return EBM_OK;
 }
 
 int ebm_timer_stop(ebm_handle_t h, float *elapsed_ms) {
     if (!h || !elapsed_ms) return fail(EBM_ERR_ARG, "ebm_timer_stop: null argument");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventRecord(h->ev1, main_stream(h)));
     HIPCHK(hipEventSynchronize(h->ev1));
     HIPCHK(hipEventElapsedTime(elapsed_ms, h->ev0, h->ev1));
     return EBM_OK;
@@ -1406,7 +1452,7 @@ int ebm_timer_stop(ebm_handle_t h, float *elapsed_ms) {
 int ebm_debug_stamps(ebm_handle_t h, unsigned long long *host) {
     if (!h) return fail(EBM_ERR_ARG, "ebm_debug_stamps: null handle");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(main_stream(h)));
     const size_t nb = sizeof(unsigned long long) * (16 + 128) * (size_t)h->ncol;
     if (!h->stamps) {
         HIPCHK(hipMalloc(&h->stamps, nb));

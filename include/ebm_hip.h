@@ -114,12 +114,18 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
  * use_graph: replay hipGraphs of 64 captured step launches in ebm_run (-1 = by size: on for steps of at most
  *   262,144 cells, which are launch-bound; 0 = off; 1 = on).  Bit-identical either way.
  * prefetch_cols: L2-prefetch distance of the MIZ step kernel in columns (-1 = the successor workgroup on the
- *   same XCD when at most two workgroups fit a CU, else off; 0 = off).  Performance only. */
+ *   same XCD when at most two workgroups fit a CU, else off; 0 = off).  Performance only.
+ * launch_chains: 1 (and -1, the default) = every step is one launch over all columns; 2 = the two halves of the columns
+ *   are stepped by two independent chains of launches on two streams, which fill each other's launch boundaries and store
+ *   tails: worth it where a CU holds a single workgroup (meridians of more than 2048 cells) and every chain still fills
+ *   the chip several times over (4096 x 2048: 0.1656 -> 0.1594 ms per step).  Columns are independent: bit-identical either
+ *   way.  ebm_get_counters counts one launch per chain and step; ignored with graph replay. */
 typedef struct ebm_options {
     int struct_bytes;
     int cells_per_thread;
     int use_graph;
     int prefetch_cols;
+    int launch_chains;
 } ebm_options;
 int ebm_options_default(ebm_options *opt);
 /* ebm_create with explicit options (opt == NULL: the defaults, i.e. exactly ebm_create). */

@@ -163,7 +163,7 @@ def test_options_are_arguments_not_environment(pkg, monkeypatch):
     lib.ebm_destroy(h)
     opt = L.Options()
     assert lib.ebm_options_default(C.byref(opt)) == 0
-    assert (opt.struct_bytes, opt.cells_per_thread, opt.use_graph, opt.prefetch_cols) == (C.sizeof(L.Options), 0, -1, -1)
+    assert (opt.struct_bytes, opt.cells_per_thread, opt.use_graph, opt.prefetch_cols, opt.launch_chains) == (C.sizeof(L.Options), 0, -1, -1, -1)
     rc, h = create(opt)
     assert rc == 0 and info(h)[:2] == [64, 4]
     lib.ebm_destroy(h)
@@ -173,11 +173,11 @@ def test_options_are_arguments_not_environment(pkg, monkeypatch):
     lib.ebm_destroy(h)
     # a caller compiled against an OLDER, shorter struct: the fields it does not have keep their defaults
     short = L.Options()
-    short.struct_bytes, short.cells_per_thread, short.use_graph, short.prefetch_cols = 8, 2, 99, -99
+    short.struct_bytes, short.cells_per_thread, short.use_graph, short.prefetch_cols, short.launch_chains = 8, 2, 99, -99, 7
     rc, h = create(short)
     assert rc == 0 and info(h)[:2] == [128, 2]
     lib.ebm_destroy(h)
-    for field, bad in (("cells_per_thread", 3), ("use_graph", 2), ("prefetch_cols", -2), ("struct_bytes", 0)):
+    for field, bad in (("cells_per_thread", 3), ("use_graph", 2), ("prefetch_cols", -2), ("struct_bytes", 0), ("launch_chains", 3)):
         o = L.Options()
         lib.ebm_options_default(C.byref(o))
         setattr(o, field, bad)
@@ -212,6 +212,47 @@ def test_results_do_not_depend_on_the_column_count(pkg):
         for k in ALL:
             assert np.array_equal(np.concatenate([halves[0][k], halves[1][k]]), whole[k], equal_nan=True), (cells, k)
             assert np.array_equal(alone[k][0], whole[k][137], equal_nan=True), (cells, k)
+
+
+@pytest.mark.parametrize("model,kind,nlat,ncol,nt", [("MIZ", "sin", 4096, 37, 1048576), ("MIZ", "sin", 300, 9, 8000), ("MIZ_IMEX", "sin", 1024, 6, 2000),
+                                                      ("Classic", "identity", 512, 5, 2000)])
+def test_two_launch_chains_give_the_same_bits(pkg, model, kind, nlat, ncol, nt):
+    """ebm_options.launch_chains = 2: the two halves of the columns are stepped by two independent chains of launches on two
+    streams.  Columns are independent, so every result — runs, fused runs, a diagnostic step in between, integrate with
+    savesol! in the step, the hemispheric means, fields set and read in between (which join the chains) — equals the
+    one-chain run bit for bit; the launch counter counts one launch per chain and step."""
+    st = pkg.SpaceTime(kind, nlat, nt, 1)
+    par = pkg.default_parameters("Classic" if model == "Classic" else "MIZ")
+    fcol = np.linspace(-2.0, 2.0, ncol)
+    names = ("E", "Tg", "T", "h") if model == "Classic" else ALL
+    out = {}
+    for chains in (1, 2):
+        with make_engine(pkg, model, st, par, ncol, launch_chains=chains, use_graph=False) as eng:
+            if model == "Classic":
+                Ts = 30.0 - 45.0 * st.x ** 2
+                eng.set_field("E", np.tile(np.where(Ts >= 0, par["cw"] * Ts, par["Lf"] * Ts / 7.5), (ncol, 1)))
+                eng.set_field("Tg", np.tile(Ts, (ncol, 1)))
+            eng.set_column_forcing(fcol)
+            eng.set_time_table(st.t)
+            eng.run(0, 30, None, True)
+            mid = eng.get_state(names)                                # joins the chains
+            eng.set_field(names[0], mid[names[0]])                    # an upload between two forked runs
+            eng.run(30, 21, None, False, steps_per_launch=(1 if model == "MIZ_IMEX" else 5))
+            eng.step(float(eng.ttab[51]), float(eng.ttab[52]), 0.25, True)
+            hm = eng.hemispheric_mean("T")
+            state = eng.get_state(names)
+            cnt = eng.counters()
+            eng.set_time_table(st.t[:16])
+            res = eng.integrate(16, 2, None, False, 4, 11, names[:3] if model == "Classic" else ("E", "T", "phi", "Ti"))
+            out[chains] = (mid, state, hm, res, cnt)
+    for a, b in zip(out[1][:2], out[2][:2]):
+        for k in names:
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert np.array_equal(out[1][2], out[2][2], equal_nan=True)
+    for k in ("raw", "winter", "summer", "avg"):
+        assert np.array_equal(out[1][3][k], out[2][3][k], equal_nan=True), k
+    assert out[1][4]["steps"] == out[2][4]["steps"] and out[2][4]["launches"] == 2 * out[1][4]["launches"]
+    assert out[1][4]["solves"] == out[2][4]["solves"]
 
 
 @pytest.mark.parametrize("nlat,ncol,nt", [(180, 5, 2000), (1000, 3, 60000), (4096, 4, 1048576)])
