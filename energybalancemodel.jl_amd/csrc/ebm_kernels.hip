@@ -1433,7 +1433,10 @@ hipError_t launch_zonal_sweep(const double *T, double *out_Z, double *out_U, con
                               hipStream_t s) {
     // one wave per workgroup: as many workgroups as the (few) lanes of this kernel allow
     dim3 grid((pitch + 63) / 64, nmember), block(64);
-    zonal_sweep_kernel<8><<<grid, block, 0, s>>>(T, out_Z, out_U, zM, zE, za, zW, nlon, pitch, rtheta);
+#ifndef EBM_ZONAL_UNR
+#define EBM_ZONAL_UNR 16         // rows of loads ahead of the recurrence (measured: 8 rows 203.2 us, 16 rows 194.2 us on 1024 x 512 x 32; -DEBM_ZONAL_UNR=n for A/B builds)
+#endif
+    zonal_sweep_kernel<EBM_ZONAL_UNR><<<grid, block, 0, s>>>(T, out_Z, out_U, zM, zE, za, zW, nlon, pitch, rtheta);
     return hipGetLastError();
 }
 

@@ -40,7 +40,7 @@ int fail(int code, const std::string &msg) {
 // ---- host transfers: pinned staging ring + a few host threads ---------------------------------------
 // The caller's buffers are pageable.  A device -> pageable copy through the runtime alone runs at 7-8 GB/s
 // (one thread faults the destination's pages in and copies); here the DMA engine fills a pinned slot while
-// the previous slot is copied on to the caller's buffer by the host threads of a small process-wide pool (up to 12).
+// the previous slot is copied on to the caller's buffer by the host threads of a small process-wide pool (up to 16).
 
 // Process-wide pool: parallel_for(n, fn) runs fn(i) for i in [0, n) on the pool's threads and returns when
 // all are done.  One caller at a time (callers serialise on `gate`).
@@ -71,7 +71,7 @@ public:
 private:
     HostPool() {
         unsigned hw = std::thread::hardware_concurrency();
-        int n = (int)std::min(12u, std::max(1u, hw));
+        int n = (int)std::min(16u, std::max(1u, hw));
         for (int i = 0; i < n; ++i) threads_.emplace_back([this] { run(); }), threads_.back().detach();
     }
     void run() {

@@ -76,16 +76,15 @@ def test_zonal_substep_has_the_closed_form_of_fourier_modes(pkg, nlat, nlon):
         mu = 4.0 * np.sin(m * dl / 2.0) ** 2
         want = T[sl] / (1.0 + a * mu)
         eU = float(np.max(np.abs(U[sl] - want))) / np.max(np.abs(A))
-        eZ = float(np.max(np.abs(Z[sl] + c * mu * want) / (1.0 + c * mu))) / np.max(np.abs(A))       # relative to the mode's own scale
+        Zexact = -(c * mu) * want
         # the circles' systems have condition number 1 + 4 a_k — 1.2e6 at the polar circle of 1024 x 512 (forward error of
         # any stable solve: up to 1e-10) — so the bar scales with it: 2e-17 x max a_k = 6e-12 there, ten times what is measured
         # (5.8e-13), and 1e-13 on the small grid
         bar = max(1e-13, 2e-17 * float(np.max(a)))
         record_error(f"zonal substep {nlat} x {nlon}: Fourier mode m = {m} against its closed form (max a_k = {float(np.max(a)):.1e})", "U", eU, bar)
         assert eU <= bar, (m, eU, bar)
-        assert eZ <= 1e-9, (m, eZ)
-        if m == 0:
-            assert np.max(np.abs(Z[sl])) <= 1e-14 * np.max(np.abs(A)) * par["cw"] / st.dt
+        # Z = (U - T) cw/dt carries U's rounding times cw/dt; for the zonally uniform mode that is all there is (Z = 0)
+        assert np.max(np.abs(Z[sl] - Zexact)) <= 2.0 * bar * np.max(np.abs(A)) * par["cw"] / st.dt + 1e-9 * np.max(np.abs(Zexact)), m
 
 
 def test_zonal_substep_arguments(pkg):
