@@ -220,7 +220,9 @@ def main():
     device = local_rank % ndev
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    # (EBM_BENCH_FORCE_DIST=1: initialise the process group even for ONE rank, so that the RCCL code path — communicator
+    #  set-up on the device, barrier, all_reduce of a device tensor, object gather — runs on a one-GPU box as well)
+    if world > 1 or (launched and os.environ.get("EBM_BENCH_FORCE_DIST") == "1"):
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
@@ -432,7 +434,7 @@ def main():
         "value": cells * world * args.steps / elapsed,
         "unit": "grid-cell-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "backend": (backend if world > 1 else None), "world_size_seen": world_seen,
+        "backend": (backend if dist is not None else None), "world_size_seen": world_seen,
         "devices_used": len({r["device"] for r in ranks}),
         "ranks": ranks,
         "ms_per_step": elapsed * 1e3 / args.steps,

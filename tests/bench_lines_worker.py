@@ -31,5 +31,17 @@ for backend in ("nccl", "gloo"):
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     out.append({"args": two, "backend": backend, "rc": r.returncode, "nlines": len(lines),
                 "line": json.loads(lines[-1]) if lines and r.returncode == 0 else None, "stderr_tail": r.stderr[-1500:]})
+# the RCCL code path with ONE rank on the one GPU (launcher + EBM_BENCH_FORCE_DIST=1): communicator set-up on the device,
+# barrier, all_reduce of a device tensor, the object gather — everything the N > 1 run does, minus a second device
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft
+port = graft.load_package().free_port()
+one = ["--gpus", "1", "--steps", "10", "--repeats", "2", "--spinup", "50", "--preroll", "0.02", "--cpu-budget", "0"]
+r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port), os.path.join(ROOT, "bench.py")] + one, capture_output=True, text=True, cwd=ROOT,
+                   env=dict(os.environ, EBM_BENCH_FORCE_DIST="1", EBM_BENCH_BACKEND="nccl", MASTER_ADDR="127.0.0.1"))
+lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+out.append({"args": one, "backend": "nccl-one-rank", "rc": r.returncode, "nlines": len(lines),
+            "line": json.loads(lines[-1]) if lines and r.returncode == 0 else None, "stderr_tail": r.stderr[-1500:]})
 with open(sys.argv[1], "w") as fh:
     json.dump(out, fh)

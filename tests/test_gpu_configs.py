@@ -429,6 +429,10 @@ def test_bench_gpus_n_starts_n_ranks(pkg):
     for i, b in enumerate(d["blocks_ms_per_step"]):
         assert abs(b - max(r["blocks_ms_per_step"][i] for r in d["ranks"])) < 1e-9 * b
     assert "32" in d["config"]["workload"] and "f[member]" in d["config"]["workload"]
+    # the RCCL path itself, one rank on the one GPU (process group forced): the calls an N-GPU run makes, all on the device
+    one = runs[7]
+    assert one["backend"] == "nccl-one-rank" and one["rc"] == 0 and one["nlines"] == 1, one["stderr_tail"]
+    assert one["line"]["backend"] == "nccl" and one["line"]["world_size_seen"] == 1 and one["line"]["n_gpus"] == 1
 
 
 def test_hysteresis_example_runs(pkg):
