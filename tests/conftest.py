@@ -31,6 +31,11 @@ def pytest_sessionstart(session):
     markexpr = session.config.getoption("-m") or ""
     if "gpu" not in markexpr or "not gpu" in markexpr:
         return
+    if os.environ.get("EBM_TEST_NO_CHILDREN") == "1":
+        # runners that start many sessions back to back (tests/tools/mutants_run.sh): a session that stops at its first
+        # failure would leave its children on the GPU while the next session starts its own — the box allows six
+        # processes on the card; the tests that read the children's output skip
+        return
     # is there a GPU?  Asked of the kernel driver's topology, not of torch / HIP: this process must not have
     # initialised the GPU when it starts the children below (energybalancemodel.jl_amd/_devices.py)
     if graft.load_package().visible_gpu_count() < 1:
@@ -59,6 +64,18 @@ def pytest_sessionstart(session):
              "--master-addr", "127.0.0.1", "--master-port", str(graft.load_package().free_port()),
              os.path.join(ROOT, "tests", "two_rank_worker.py"), TWO_RANK["out"]],
             env=env, stdout=log, stderr=subprocess.STDOUT)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """A session that ends early (-x) must not leave its children on the GPU: end exactly the processes started above."""
+    for child in (TWO_RANK, C_EXAMPLE, BENCH_LINES):
+        proc = child.get("proc")
+        if proc is not None and proc.poll() is None:
+            proc.terminate()
+            try:
+                proc.wait(timeout=30)
+            except Exception:
+                proc.kill()
 
 
 @pytest.fixture(scope="session")

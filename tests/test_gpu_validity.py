@@ -255,6 +255,29 @@ def test_two_launch_chains_give_the_same_bits(pkg, model, kind, nlat, ncol, nt):
     assert out[1][4]["solves"] == out[2][4]["solves"]
 
 
+def test_two_launch_chains_wait_for_what_the_handle_did_before(pkg):
+    """The second chain runs on a stream of its own; before its first launch after anything else the handle did, it has to
+    wait for that work.  The case with teeth: the year end of ebm_integrate on a grid large enough that its finish-mean launch
+    (which reads, averages and ZEROES the running sums of every saved variable) is still running when the next year's first
+    step is launched — a second chain that did not wait would add into sums that are then zeroed under it.  Annual means of
+    three 8-step years, one chain against two, bit for bit."""
+    nlat, ncol, nt, years = 1024, 4096, 65536, 3
+    st = pkg.SpaceTime("sin", nlat, nt, 1)
+    par = pkg.default_parameters("MIZ")
+    fcol = np.linspace(-2.0, 2.0, ncol)
+    out = {}
+    for chains in (1, 2):
+        with make_engine(pkg, "MIZ", st, par, ncol, launch_chains=chains, use_graph=False) as eng:
+            eng.set_column_forcing(fcol)
+            eng.set_time_table(st.t)
+            eng.run(0, 40, None, False)
+            eng.set_time_table(st.t[:8])
+            res = eng.integrate(8, years, None, True, 0, 0, ("E", "T", "phi", "Ew", "h", "Ei"), want_raw=False, want_seasonal=False)
+            out[chains] = res["avg"]
+    assert np.array_equal(out[1], out[2], equal_nan=True)
+    assert np.isfinite(out[1][2]).all() and np.any(out[1][2] > 0)
+
+
 @pytest.mark.parametrize("nlat,ncol,nt", [(180, 5, 2000), (1000, 3, 60000), (4096, 4, 1048576)])
 def test_diagnostic_fields_read_back_in_the_natural_layout(pkg, nlat, ncol, nt):
     """The step kernels store the diagnostic fields in a layout of their own (whole lines per store instruction); every

@@ -77,6 +77,26 @@ MUTANTS = [
     ("parked_first_pair_takes_D_for_h", "sEw[0] = v0 ? o[0].q[Q_h] : 0.0;  sEw[T] = v1 ? o[1].q[Q_h] : 0.0;", "sEw[0] = v0 ? o[0].q[Q_D] : 0.0;  sEw[T] = v1 ? o[1].q[Q_h] : 0.0;"),
     ("classic_ghost_diagonal_ignores_the_melting_mask", "const double q = bool_mul(bool_mul(ieee_div(p.dc, den), T0 < 0.0), Ek < 0.0);", "const double q = bool_mul(ieee_div(p.dc, den), Ek < 0.0);"),
     ("classic_surface_temperature_sign", "const double T0 = ieee_div(Cc, p.M - ieee_div(p.kLf, Ek));", "const double T0 = ieee_div(Cc, p.M + ieee_div(p.kLf, Ek));"),
+    # sixth batch (round 3): the private store layout of the diagnostic fields, validity tracking, launch chains, the pinned
+    # ring, model time across integrate calls, the zonal sweep and its tables
+    ("unsplit_writes_the_first_pair_twice", "*reinterpret_cast<double2 *>(f + 4 * t + 2) = p1;", "*reinterpret_cast<double2 *>(f + 4 * t + 2) = p0;"),
+    ("diagnostic_pairs_stored_on_top_of_each_other", "const unsigned ks = (unsigned)(j * 2 * T + 2 * t);", "const unsigned ks = (unsigned)(2 * t);"),
+    ("diagnostic_layout_flag_never_set", "if (write_diag && h->model == EBM_MODEL_MIZ) h->diag_split = h->cfg.cells == 4;",
+     "if (write_diag && h->model == EBM_MODEL_MIZ) h->diag_split = false;", "ebm_runtime.hip"),
+    ("fields_never_go_stale", "    h->epoch += nsteps;", "    h->epoch += 0;", "ebm_runtime.hip"),
+    ("classic_kernel_ignores_its_column_offset", "const int T = blockDim.x, t = threadIdx.x, col = a.col0 + (int)blockIdx.x;",
+     "const int T = blockDim.x, t = threadIdx.x, col = (int)blockIdx.x;"),
+    ("launch_chains_never_joined", "        (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);", "", "ebm_runtime.hip"),
+    ("second_chain_does_not_wait_for_earlier_work", "if (e == hipSuccess) e = hipStreamWaitEvent(h->stream2, h->ev_fork, 0);", "", "ebm_runtime.hip"),
+    ("zonal_last_row_coefficient_sign", "            f = -a * ee[i];", "            f = a * ee[i];"),
+    ("zonal_back_substitution_drops_the_wrap_term", "const double U = __builtin_fma(a * mm[i], Un, __builtin_fma(ee[i], W, dd[i]));",
+     "const double U = __builtin_fma(a * mm[i], Un, dd[i]);"),
+    ("zonal_coefficient_linear_in_dlambda", "a = theta * h->p.D / (m * (dl * dl));", "a = theta * h->p.D / (m * dl);", "ebm_runtime.hip"),
+    ("annual_means_all_from_the_first_variable", "const size_t base = (size_t)blockIdx.y * (size_t)var_stride + (size_t)col * (size_t)threads * cells;",
+     "const size_t base = (size_t)col * (size_t)threads * cells;"),
+    ("ring_pieces_reuse_the_first_two_offsets", "const size_t r0 = i * rows_per;", "const size_t r0 = (i % 2) * rows_per;", "ebm_runtime.hip"),
+    ("integrate_restarts_model_time", "f, diag, clock0 + tinx - 1,", "f, diag, tinx - 1,", "ebm_runtime.hip"),
+    ("as_of_query_inverted", "    if (have != step)", "    if (have == step)", "ebm_runtime.hip"),
 ]
 
 
