@@ -16,13 +16,42 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-# The 2-process Engine test needs a fresh pair of ranks started BEFORE this process has touched the
-# GPU (a process that has initialised HIP must not spawn the launcher: on this pool an exec from such
-# a process is refused).  So the launcher is started here, at session start, whenever GPU tests are
-# selected and a device is present; tests/test_gpu_configs.py waits for it and checks its output.
+# Several GPU tests need OTHER processes on the GPU — a fresh pair of torch.distributed ranks, a plain-C program, bench.py
+# itself, an example — and a process that has initialised HIP must not start a launcher (on this pool an exec from such a
+# process is refused).  So ONE child, tests/session_children.py, is started here, at session start, before this process
+# touches the GPU; it runs those jobs one after the other (the box allows six processes on the card: pytest plus at most two
+# ranks of the child's current job) and leaves a `<stage>.done` file as each finishes.  The tests wait for their stage.
+class Stage:
+    """`proc`-like handle of one stage of the session's child: wait() returns the stage's return code."""
+
+    def __init__(self, worker, done_path):
+        self.worker, self.done_path = worker, done_path
+
+    def poll(self):
+        if os.path.exists(self.done_path):
+            import json
+            try:
+                return json.load(open(self.done_path))["rc"]
+            except ValueError:
+                return None                     # being written
+        return None
+
+    def wait(self, timeout=900):
+        import time
+        t0 = time.time()
+        while time.time() - t0 < timeout:
+            rc = self.poll()
+            if rc is not None:
+                return rc
+            if self.worker.poll() is not None and self.poll() is None:
+                return -999                     # the child ended without reaching this stage
+            time.sleep(0.2)
+        raise TimeoutError(self.done_path)
+
+
 TWO_RANK = {"proc": None, "out": None, "log": None}
-C_EXAMPLE = {"proc": None, "out": None, "err": None}      # examples/c_abi_example.c, same reason
-BENCH_LINES = {"proc": None, "out": None}                 # tests/bench_lines_worker.py, same reason
+C_EXAMPLE = {"proc": None, "out": None, "err": None}      # examples/c_abi_example.c
+BENCH_LINES = {"proc": None, "out": None}                 # the child itself: its last stage writes the bench lines
 
 
 def pytest_sessionstart(session):
@@ -32,19 +61,15 @@ def pytest_sessionstart(session):
     if "gpu" not in markexpr or "not gpu" in markexpr:
         return
     if os.environ.get("EBM_TEST_NO_CHILDREN") == "1":
-        # runners that start many sessions back to back (tests/tools/mutants_run.sh): a session that stops at its first
-        # failure would leave its children on the GPU while the next session starts its own — the box allows six
-        # processes on the card; the tests that read the children's output skip
+        # runners that start many sessions back to back (tests/tools/mutants_run.sh): the tests that read the child's
+        # output skip
         return
     # is there a GPU?  Asked of the kernel driver's topology, not of torch / HIP: this process must not have
-    # initialised the GPU when it starts the children below (energybalancemodel.jl_amd/_devices.py)
+    # initialised the GPU when it starts the child below (energybalancemodel.jl_amd/_devices.py)
     if graft.load_package().visible_gpu_count() < 1:
         return
-    tmp = tempfile.mkdtemp(prefix="ebm_two_rank_")
-    TWO_RANK["out"] = os.path.join(tmp, "gathered.npz")
-    TWO_RANK["log"] = os.path.join(tmp, "two_rank.log")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    # the plain-C caller of the ABI: build with gcc, run as a child (tests/test_gpu_configs.py checks it)
+    tmp = tempfile.mkdtemp(prefix="ebm_session_")
+    # the plain-C caller of the ABI: build with gcc here, the child runs it (tests/test_gpu_configs.py checks it)
     exe = os.path.join(tmp, "c_abi_example")
     libdir = os.path.join(ROOT, "energybalancemodel.jl_amd")
     build = subprocess.run(
@@ -52,30 +77,29 @@ def pytest_sessionstart(session):
          "-o", exe, "-L", libdir, "-lebm_hip", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
          "-Wl,-rpath-link,/opt/rocm/lib"], capture_output=True, text=True)
     C_EXAMPLE["err"] = build.stderr
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "session_children.py"), tmp, exe if build.returncode == 0 else "-"],
+                              env=env, stdout=subprocess.DEVNULL, stderr=open(os.path.join(tmp, "session_children.err"), "w"))
     if build.returncode == 0:
         C_EXAMPLE["out"] = os.path.join(tmp, "c_abi_example.out")
-        C_EXAMPLE["proc"] = subprocess.Popen([exe], stdout=open(C_EXAMPLE["out"], "w"), stderr=subprocess.STDOUT)
+        C_EXAMPLE["proc"] = Stage(worker, os.path.join(tmp, "c_example.done"))
+    TWO_RANK["out"] = os.path.join(tmp, "gathered.npz")
+    TWO_RANK["log"] = os.path.join(tmp, "two_rank.log")
+    TWO_RANK["proc"] = Stage(worker, os.path.join(tmp, "two_rank.done"))
     BENCH_LINES["out"] = os.path.join(tmp, "bench_lines.json")
-    BENCH_LINES["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "bench_lines_worker.py"), BENCH_LINES["out"]],
-                                           env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    with open(TWO_RANK["log"], "w") as log:
-        TWO_RANK["proc"] = subprocess.Popen(
-            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-             "--master-addr", "127.0.0.1", "--master-port", str(graft.load_package().free_port()),
-             os.path.join(ROOT, "tests", "two_rank_worker.py"), TWO_RANK["out"]],
-            env=env, stdout=log, stderr=subprocess.STDOUT)
+    BENCH_LINES["proc"] = worker
 
 
 def pytest_sessionfinish(session, exitstatus):
-    """A session that ends early (-x) must not leave its children on the GPU: end exactly the processes started above."""
-    for child in (TWO_RANK, C_EXAMPLE, BENCH_LINES):
-        proc = child.get("proc")
-        if proc is not None and proc.poll() is None:
-            proc.terminate()
-            try:
-                proc.wait(timeout=30)
-            except Exception:
-                proc.kill()
+    """A session that ends early (-x) must not leave its child on the GPU: end exactly the process started above (it ends
+    the job it is running, tests/session_children.py)."""
+    proc = BENCH_LINES.get("proc")
+    if proc is not None and proc.poll() is None:
+        proc.terminate()
+        try:
+            proc.wait(timeout=40)
+        except Exception:
+            proc.kill()
 
 
 @pytest.fixture(scope="session")
