@@ -677,47 +677,56 @@ __global__ void __launch_bounds__(TT, 4) miz_step_kernel(const StepArgs a) {
 
     // ---------------- phase A: loads, water temperature, T0-system coefficients ----------
     // Only phi and the right-hand side stay in registers across the solve; Ew, h, Tw wait in the
-    // LDS stash.  The (rare: < 0.1 % of column-steps) second and later Newton iterations simply run
-    // phase A again with the new active set — one copy of the code, nothing extra kept alive.
+    // LDS stash.  The second and later Newton iterations (a changed active set: < 0.1 % of column-steps at the
+    // reference's time steps, every second one with the extension's long ones) form the rows again from the stashed h
+    // and the two coefficient tables and call the same solve — one copy of the solve in the kernel.
     double ph[C], rd[C], xs[C];
     unsigned smask = cmask[t];                            // active set: bit i <=> T0_i < Tm
     int it = 0;
     bool again;
     do {
-        double Ew[C], hk[C], xk[C], tlo[C], tup[C], dd[C], r[C];
+        double tlo[C], tup[C], dd[C];
         // (the lane's cell index is made opaque inside the loop: hoisted out of it, the six addresses
         // would live as per-lane 64-bit pointers instead of the wave-uniform base + 32-bit offset form)
         unsigned kl = k0;
         asm volatile("" : "+v"(kl));
-        load_chunk<C>(st + S_Ew * a.fstride, kl, Ew);
-        load_chunk<C>(st + S_phi * a.fstride, kl, ph);
-        load_chunk<C>(st + S_h * a.fstride, kl, hk);
-        load_chunk<C>(gX, kl, xk);
         load_chunk<C>(a.geom + G_LO * a.gstride, kl, tlo);
         load_chunk<C>(a.geom + G_UP * a.gstride, kl, tup);
-        // Padding cells (k >= nlat) need no special case in phases A and B: their state and table
-        // entries are zero, so their rows are decoupled (lo = up = 0, g = phi = 0) and finite.
+        if (it == 0) {
+            double Ew[C], hk[C], xk[C], r[C];
+            load_chunk<C>(st + S_Ew * a.fstride, kl, Ew);
+            load_chunk<C>(st + S_phi * a.fstride, kl, ph);
+            load_chunk<C>(st + S_h * a.fstride, kl, hk);
+            load_chunk<C>(gX, kl, xk);
+            // Padding cells (k >= nlat) need no special case in phases A and B: their state and table
+            // entries are zero, so their rows are decoupled (lo = up = 0, g = phi = 0) and finite.
 #pragma unroll
-        for (int i = 0; i < C; ++i) {
-            const double tw = water_temperature(p, Ew[i], ph[i]);
-            sEw[i * T] = Ew[i];
-            sh[i * T] = hk[i];
-            sTw[i * T] = tw;
-            dd[i] = t0_diag_excess(p, hk[i]);
-            r[i] = (1.0 - ph[i]) * (tw - Tm);
-        }
-        EBM_STAMP(1);
-        EBM_STAMPW(1);                                    // per wave: inputs arrived
-        double rl, rr;
-        halo_exchange(P0, P0 + T, t, T, r[0], r[C - 1], rl, rr);
-        EBM_STAMP(2);
+            for (int i = 0; i < C; ++i) {
+                const double tw = water_temperature(p, Ew[i], ph[i]);
+                sEw[i * T] = Ew[i];
+                sh[i * T] = hk[i];
+                sTw[i * T] = tw;
+                dd[i] = t0_diag_excess(p, hk[i]);
+                r[i] = (1.0 - ph[i]) * (tw - Tm);
+            }
+            EBM_STAMP(1);
+            EBM_STAMPW(1);                                    // per wave: inputs arrived
+            double rl, rr;
+            halo_exchange(P0, P0 + T, t, T, r[0], r[C - 1], rl, rr);
+            EBM_STAMP(2);
 #pragma unroll
-        for (int i = 0; i < C; ++i) {
-            const double rm = i > 0 ? r[i > 0 ? i - 1 : 0] : rl;
-            const double rp = i < C - 1 ? r[i < C - 1 ? i + 1 : i] : rr;
-            rd[i] = t0_rhs(p, insolation(p, xk[i], ct), tlo[i], tup[i], rm, r[i], rp, f);
+            for (int i = 0; i < C; ++i) {
+                const double rm = i > 0 ? r[i > 0 ? i - 1 : 0] : rl;
+                const double rp = i < C - 1 ? r[i < C - 1 ? i + 1 : i] : rr;
+                rd[i] = t0_rhs(p, insolation(p, xk[i], ct), tlo[i], tup[i], rm, r[i], rp, f);
+            }
+            __syncthreads();                                  // r halo reads done before P0 is reused
+        } else {
+            // second and later iterations (a changed active set): the right-hand side does not depend on the set and
+            // is still in registers, like phi; only the rows' ingredients are fetched / formed again — the same values
+#pragma unroll
+            for (int i = 0; i < C; ++i) dd[i] = t0_diag_excess(p, sh[i * T]);
         }
-        __syncthreads();                                  // r halo reads done before P0 is reused
         EBM_STAMP(3);
         // ---------------- phase B: active-set Newton, src/miz.jl:33-68 --------------------
         ++it;
