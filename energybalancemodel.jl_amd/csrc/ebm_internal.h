@@ -145,6 +145,13 @@ hipError_t launch_finish_mean(double *dst, double *sum, double nt, int ncol, int
 hipError_t launch_zonal_sweep(const double *T, double *out_Z, double *out_U, const double *zM, const double *zE,
                               const double *za, const double *zW, int nlon, int nmember, int pitch, double rtheta,
                               hipStream_t s);
+// The same systems partitioned along the circle into S segments (circles of >= 256 longitudes): chain tables cM, cE
+// [nlon/S - 1][pitch] of one segment, reduced-system tables rM, rE [S - 1][pitch], za, za2, rW [pitch]; su, sg, sy are
+// scratch [nmember][S][pitch].  Three launches.
+hipError_t launch_zonal_sweep_segmented(const double *T, double *out_Z, double *out_U, const double *cM, const double *cE,
+                                        const double *rM, const double *rE, const double *za, const double *za2,
+                                        const double *rW, double *su, double *sg, double *sy, int nlon, int S, int nmember,
+                                        int pitch, double rtheta, hipStream_t s);
 // natural <-> pair-split layout of whole fields ([ncol][pitch], 4 cells per thread; a no-op with 2), in place
 hipError_t launch_split_fields(double *fields, long long field_stride, int nfields, int ncol, const LaunchCfg &cfg,
                                hipStream_t s);

@@ -1357,6 +1357,9 @@ hipError_t launch_split_fields(double *fields, long long field_stride, int nfiel
 // diagonal.  m_l, ep_l and zW depend on (latitude, l) only and come from tables built at ebm_create (zM, zE, zW); a = za.
 // Forward sweep: dp_l is parked in the output array; backward sweep: U_l, then Z_l = (U_l - b_l) cw/dt over it.
 // Free arithmetic (fma): the result is defined by the linear system.  UNR rows are loaded ahead of the recurrence.
+#ifndef EBM_ZONAL_UNR
+#define EBM_ZONAL_UNR 16         // rows of loads ahead of the recurrence (measured: 8 rows 203.2 us, 16 rows 194.2 us on 1024 x 512 x 32; -DEBM_ZONAL_UNR=n for A/B builds)
+#endif
 template <int UNR>
 __global__ void __launch_bounds__(256) zonal_sweep_kernel(const double *__restrict__ T, double *__restrict__ out_Z,
                                                           double *__restrict__ out_U, const double *__restrict__ zM,
@@ -1442,10 +1445,159 @@ hipError_t launch_zonal_sweep(const double *T, double *out_Z, double *out_U, con
                               hipStream_t s) {
     // one wave per workgroup: as many workgroups as the (few) lanes of this kernel allow
     dim3 grid((pitch + 63) / 64, nmember), block(64);
-#ifndef EBM_ZONAL_UNR
-#define EBM_ZONAL_UNR 16         // rows of loads ahead of the recurrence (measured: 8 rows 203.2 us, 16 rows 194.2 us on 1024 x 512 x 32; -DEBM_ZONAL_UNR=n for A/B builds)
-#endif
     zonal_sweep_kernel<EBM_ZONAL_UNR><<<grid, block, 0, s>>>(T, out_Z, out_U, zM, zE, za, zW, nlon, pitch, rtheta);
+    return hipGetLastError();
+}
+
+// ---- the same periodic systems, partitioned along the circle ----------------------------------------------------------
+// One lane per (member, latitude) gives nlat x nmember lanes: 64 waves for a single 4096 x 2048 grid.  For circles of 256
+// longitudes and more the circle is cut into S segments of m = nlon/S unknowns (S a function of nlon only), each walked by
+// its own lane — the column solve's partition, across longitude:
+//   1. zonal_seg_forward: inside segment s, rows 0 .. m-2 are eliminated as above with the segment's LEFT neighbour
+//      L = y_{s-1} in the role of the wrap unknown:  U_i = dp_i + ep_i L + cp_i U_{i+1}; dp_i is parked, and
+//      u_s = sum_i P_i dp_i (P_i = cp_0 ... cp_{i-1}: the segment's first unknown for L = y_s = 0) and
+//      g_s = b_{m-1} + a dp_{m-2} are kept per segment;
+//   2. zonal_reduced_solve: the segments' last unknowns y_s obey a periodic tridiagonal system of size S with CONSTANT
+//      coefficients again,  -a'' y_{s-1} + B'' y_s - a'' y_{s+1} = g_s + a u_{s+1},   a'' = a ep_{m-2},
+//      B'' = B - a cp_{m-2} - a alpha,  alpha = sum_i P_i ep_i  — solved per (member, latitude) by the same elimination;
+//   3. zonal_seg_backward: back-substitution inside every segment from y_s and y_{s-1}, and Z.
+// Tables: the chain's m_i, ep_i for ONE segment ([m-1][pitch], cache resident whatever nlon is), the reduced system's
+// ([S-1][pitch]) and a, a'', the reciprocal of the reduced last diagonal per latitude.
+template <int UNR>
+__global__ void __launch_bounds__(256) zonal_seg_forward_kernel(const double *__restrict__ T, double *__restrict__ out_Z,
+                                                                const double *__restrict__ cM, const double *__restrict__ cE,
+                                                                const double *__restrict__ za, double *__restrict__ su,
+                                                                double *__restrict__ sg, int nlon, int S, int pitch) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= pitch) return;
+    const int seg = blockIdx.y % S, member = blockIdx.y / S, m = nlon / S;
+    const size_t P = (size_t)pitch;
+    const size_t row0 = ((size_t)member * (size_t)nlon + (size_t)seg * (size_t)m) * P + (size_t)p;
+    const double *b = T + row0;
+    double *d = out_Z + row0;
+    const double *M = cM + p, *E = cE + p;
+    const double a = za[p];
+    double dp = b[0] * M[0];
+    double u = dp;                                   // P_0 = 1
+    int i = 0;
+    for (; i + UNR <= m - 2; i += UNR) {             // rows i+1 .. i+UNR <= m-2
+        double bb[UNR], mm[UNR], ee[UNR];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            bb[k] = b[(size_t)(i + 1 + k) * P];
+            mm[k] = M[(size_t)(i + 1 + k) * P];
+            ee[k] = E[(size_t)(i + k) * P];          // P_{i+1+k} = ep_{i+k}
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            d[(size_t)(i + k) * P] = dp;
+            dp = __builtin_fma(a, dp, bb[k]) * mm[k];
+            u = __builtin_fma(ee[k], dp, u);
+        }
+    }
+    for (; i < m - 2; ++i) {
+        d[(size_t)i * P] = dp;
+        dp = __builtin_fma(a, dp, b[(size_t)(i + 1) * P]) * M[(size_t)(i + 1) * P];
+        u = __builtin_fma(E[(size_t)i * P], dp, u);
+    }
+    d[(size_t)(m - 2) * P] = dp;                     // dp_{m-2}
+    const size_t so = ((size_t)member * (size_t)S + (size_t)seg) * P + (size_t)p;
+    su[so] = u;
+    sg[so] = __builtin_fma(a, dp, b[(size_t)(m - 1) * P]);
+}
+
+// the reduced periodic system of the S segment ends, per (member, latitude); sy holds dp on the way and y at the end
+__global__ void __launch_bounds__(256) zonal_reduced_solve_kernel(const double *__restrict__ su, const double *__restrict__ sg,
+                                                                  double *__restrict__ sy, const double *__restrict__ rM,
+                                                                  const double *__restrict__ rE, const double *__restrict__ za,
+                                                                  const double *__restrict__ za2, const double *__restrict__ rW,
+                                                                  int S, int pitch) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= pitch) return;
+    const size_t P = (size_t)pitch;
+    const size_t o = (size_t)blockIdx.y * (size_t)S * P + (size_t)p;
+    const double a = za[p], a2 = za2[p];
+    auto rhs = [&](int s_) { return __builtin_fma(a, su[o + (size_t)((s_ + 1) % S) * P], sg[o + (size_t)s_ * P]); };
+    const double *M = rM + p, *E = rE + p;
+    double dp = rhs(0) * M[0];
+    double R = 0.0, f = -a2;
+    for (int l = 0; l < S - 2; ++l) {
+        sy[o + (size_t)l * P] = dp;
+        R = __builtin_fma(-f, dp, R);
+        f = -a2 * E[(size_t)l * P];
+        dp = __builtin_fma(a2, dp, rhs(l + 1)) * M[(size_t)(l + 1) * P];
+    }
+    const double W = (rhs(S - 1) + R - (f - a2) * dp) * rW[p];
+    sy[o + (size_t)(S - 1) * P] = W;
+    double Un = W;
+    {
+        const int l = S - 2;
+        const double U = __builtin_fma(a2 * M[(size_t)l * P], Un, __builtin_fma(E[(size_t)l * P], W, dp));
+        sy[o + (size_t)l * P] = U;
+        Un = U;
+    }
+    for (int l = S - 3; l >= 0; --l) {
+        const double U = __builtin_fma(a2 * M[(size_t)l * P], Un, __builtin_fma(E[(size_t)l * P], W, sy[o + (size_t)l * P]));
+        sy[o + (size_t)l * P] = U;
+        Un = U;
+    }
+}
+
+template <int UNR>
+__global__ void __launch_bounds__(256) zonal_seg_backward_kernel(const double *__restrict__ T, double *__restrict__ out_Z,
+                                                                 double *__restrict__ out_U, const double *__restrict__ cM,
+                                                                 const double *__restrict__ cE, const double *__restrict__ za,
+                                                                 const double *__restrict__ sy, int nlon, int S, int pitch,
+                                                                 double rtheta) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= pitch) return;
+    const int seg = blockIdx.y % S, member = blockIdx.y / S, m = nlon / S;
+    const size_t P = (size_t)pitch;
+    const size_t row0 = ((size_t)member * (size_t)nlon + (size_t)seg * (size_t)m) * P + (size_t)p;
+    const double *b = T + row0;
+    double *d = out_Z + row0;
+    double *uo = out_U ? out_U + row0 : nullptr;
+    const double *M = cM + p, *E = cE + p;
+    const double a = za[p];
+    const size_t so = (size_t)member * (size_t)S * P + (size_t)p;
+    const double y = sy[so + (size_t)seg * P], L = sy[so + (size_t)((seg + S - 1) % S) * P];
+    d[(size_t)(m - 1) * P] = (y - b[(size_t)(m - 1) * P]) * rtheta;
+    if (uo) uo[(size_t)(m - 1) * P] = y;
+    double Un = y;
+    int l = m - 2;
+    for (; l - UNR + 1 >= 0; l -= UNR) {
+        double bb[UNR], mm[UNR], ee[UNR], dd[UNR];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            bb[k] = b[(size_t)(l - k) * P];
+            mm[k] = M[(size_t)(l - k) * P];
+            ee[k] = E[(size_t)(l - k) * P];
+            dd[k] = d[(size_t)(l - k) * P];
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const double U = __builtin_fma(a * mm[k], Un, __builtin_fma(ee[k], L, dd[k]));
+            d[(size_t)(l - k) * P] = (U - bb[k]) * rtheta;
+            if (uo) uo[(size_t)(l - k) * P] = U;
+            Un = U;
+        }
+    }
+    for (; l >= 0; --l) {
+        const double U = __builtin_fma(a * M[(size_t)l * P], Un, __builtin_fma(E[(size_t)l * P], L, d[(size_t)l * P]));
+        d[(size_t)l * P] = (U - b[(size_t)l * P]) * rtheta;
+        if (uo) uo[(size_t)l * P] = U;
+        Un = U;
+    }
+}
+
+hipError_t launch_zonal_sweep_segmented(const double *T, double *out_Z, double *out_U, const double *cM, const double *cE,
+                                        const double *rM, const double *rE, const double *za, const double *za2,
+                                        const double *rW, double *su, double *sg, double *sy, int nlon, int S, int nmember,
+                                        int pitch, double rtheta, hipStream_t s) {
+    dim3 block(64), gseg((pitch + 63) / 64, S * nmember), gred((pitch + 63) / 64, nmember);
+    zonal_seg_forward_kernel<EBM_ZONAL_UNR><<<gseg, block, 0, s>>>(T, out_Z, cM, cE, za, su, sg, nlon, S, pitch);
+    zonal_reduced_solve_kernel<<<gred, block, 0, s>>>(su, sg, sy, rM, rE, za, za2, rW, S, pitch);
+    zonal_seg_backward_kernel<EBM_ZONAL_UNR><<<gseg, block, 0, s>>>(T, out_Z, out_U, cM, cE, za, sy, nlon, S, pitch, rtheta);
     return hipGetLastError();
 }
 

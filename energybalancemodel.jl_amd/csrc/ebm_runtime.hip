@@ -95,8 +95,10 @@ struct ebm_ctx {
     // the first reader after such a step runs the in-place un-permutation once.
     bool diag_split = false;
     // ebm_zonal_diffusion: the tables of the last nlon used, kept between calls
-    int nlon = 0;
-    double *ztab = nullptr;                        // zM | zE ([nlon][pitch] each) | za | zW ([pitch] each), store index space
+    int nlon = 0, zseg = 1;                        // zseg: segments a circle is cut into (a function of nlon only)
+    double *ztab = nullptr;                        // chain tables | reduced-system tables | per-latitude scalars | scratch (build_zonal_tables)
+    double *zM = nullptr, *zE = nullptr, *zrM = nullptr, *zrE = nullptr, *za = nullptr, *za2 = nullptr, *zW = nullptr,
+           *zsu = nullptr, *zsg = nullptr, *zsy = nullptr;       // views into ztab
     std::vector<double> xhost;                     // st.x (the zonal tables are built on demand)
     HostCopier *copier = nullptr;                  // pinned staging ring, lazily created by the first host transfer
     double *scratch = nullptr;                     // ebm_diffusion: temp | base | out, kept between calls
@@ -265,18 +267,54 @@ void fill_params(ebm::Params &p, const double *v, double dt) {
     p.theta_imex = dt / p.cw;            // EBM_MODEL_MIZ_IMEX: the solve's matrix is I - theta*Dif
 }
 
-// Tables of the zonal substep (ebm_zonal_diffusion, include/ebm_hip.h; kernel: zonal_sweep_kernel): per latitude the
-// coefficient a_k = (dt/cw) D / ((1 - x_k)(1 + x_k) dlambda^2) and the data-independent part of the periodic Thomas
-// elimination (m_l, ep_l, the reciprocal of the reduced last diagonal), stored in the handle's store index space: with 4
-// cells per thread entry p = j*2T + 2t + q belongs to latitude k = 4t + 2j + q (pair-split), with 2 cells p = k; padding
-// latitudes get a = 0 (U = temp, Z = 0).  Built on first use and whenever nlon changes.
+// Segments a latitude circle of nlon unknowns is cut into (zonal_seg_* kernels): a power of two between 4 and 32 that
+// leaves segments of at least 64 unknowns, else 1 (zonal_sweep_kernel walks the whole circle).  A function of nlon ONLY —
+// like the column geometry, never of how many members share the handle.
+int zonal_segments(int nlon) {
+    int S = 1;
+    for (int c = 4; c <= 32; c *= 2)
+        if (nlon % c == 0 && nlon / c >= 64) S = c;
+    return S;
+}
+
+// Data-independent part of the periodic Thomas elimination of the system (-a, B, -a) of n unknowns (see zonal_sweep_kernel):
+// m_l and ep_l for l = 0 .. n-2 into M / E (stride P), the reciprocal of the reduced last diagonal into *W.
+void periodic_tables(double a, double B, int n, double *M, double *E, size_t P, double *W) {
+    double cp_prev = 0.0, ep_prev = 0.0, gW = 0.0, f = -a, cp = 0.0, ep = 0.0;
+    for (int l = 0; l <= n - 2; ++l) {
+        const double m = 1.0 / (l == 0 ? B : B - a * cp_prev);
+        cp = a * m;
+        ep = l == 0 ? cp : a * ep_prev * m;
+        M[(size_t)l * P] = m;
+        E[(size_t)l * P] = ep;
+        if (l <= n - 3) {
+            gW += f * ep;
+            f = -a * ep;                // f_{l+1} = f_l cp_l = -a ep_l
+        }
+        cp_prev = cp;
+        ep_prev = ep;
+    }
+    *W = 1.0 / (B + gW + (f - a) * (cp + ep));       // f = f_{n-2}, cp / ep = those of row n-2
+}
+
+// Tables of the zonal substep (ebm_zonal_diffusion, include/ebm_hip.h; kernels: zonal_sweep_kernel, zonal_seg_*): per
+// latitude the coefficient a_k = (dt/cw) D / ((1 - x_k)(1 + x_k) dlambda^2) and the data-independent part of the
+// elimination, stored in the handle's store index space: with 4 cells per thread entry p = j*2T + 2t + q belongs to
+// latitude k = 4t + 2j + q (pair-split), with 2 cells p = k; padding latitudes get a = 0 (U = temp, Z = 0).  One segment
+// (S = 1): the whole circle's chain with its wrap closure.  S > 1: the chain of ONE segment of m = nlon/S unknowns (open
+// ends), and the reduced periodic system of the S segment ends, (-a'', B'', -a'') with a'' = a ep_{m-2},
+// B'' = B - a cp_{m-2} - a alpha, alpha = sum_i P_i ep_i.  Built on first use and whenever nlon changes.
 int build_zonal_tables(ebm_ctx *h, int nlon) {
     if (h->ztab && h->nlon == nlon) return EBM_OK;
-    const int n = nlon, P = (int)h->pitch, T = h->cfg.threads;
+    const int S = zonal_segments(nlon), m = nlon / S, P = (int)h->pitch, T = h->cfg.threads;
+    const int nmember = h->ncol / nlon;
     const double *x = h->xhost.data();
-    const double dl = 2.0 * M_PI / n, theta = h->dt / h->p.cw;
-    std::vector<double> tab((size_t)2 * n * P + 2 * (size_t)P, 0.0);
-    double *zM = tab.data(), *zE = zM + (size_t)n * P, *za = zE + (size_t)n * P, *zW = za + P;
+    const double dl = 2.0 * M_PI / nlon, theta = h->dt / h->p.cw;
+    const size_t chain_rows = (size_t)(S == 1 ? nlon : m), red_rows = (size_t)(S == 1 ? 0 : S);
+    const size_t scratch = S == 1 ? 0 : 3 * (size_t)nmember * S * P;
+    std::vector<double> tab(2 * chain_rows * P + 2 * red_rows * P + 3 * (size_t)P, 0.0);
+    double *zM = tab.data(), *zE = zM + chain_rows * P, *rM = zE + chain_rows * P, *rE = rM + red_rows * P,
+           *za = rE + red_rows * P, *za2 = za + P, *zW = za2 + P;
     for (int p = 0; p < P; ++p) {
         int k = p;
         if (h->cfg.cells == 4) {
@@ -285,41 +323,46 @@ int build_zonal_tables(ebm_ctx *h, int nlon) {
         }
         double a = 0.0;
         if (k < h->nlat) {
-            const double m = (1.0 - x[k]) * (1.0 + x[k]);        // 1 - x^2 without the cancellation near the pole
-            if (!(m > 0.0)) return fail(EBM_ERR_ARG, "ebm_zonal_diffusion: needs |x| < 1 at every cell centre (the zonal coefficient is D/(1-x^2))");
-            a = theta * h->p.D / (m * (dl * dl));
+            const double mm = (1.0 - x[k]) * (1.0 + x[k]);       // 1 - x^2 without the cancellation near the pole
+            if (!(mm > 0.0)) return fail(EBM_ERR_ARG, "ebm_zonal_diffusion: needs |x| < 1 at every cell centre (the zonal coefficient is D/(1-x^2))");
+            a = theta * h->p.D / (mm * (dl * dl));
         }
         const double B = 1.0 + 2.0 * a;
-        double cp_prev = 0.0, ep_prev = 0.0, gW = 0.0, f = -a, cp = 0.0, ep = 0.0;
-        for (int l = 0; l <= n - 2; ++l) {
-            const double m = 1.0 / (l == 0 ? B : B - a * cp_prev);
-            cp = a * m;
-            ep = l == 0 ? cp : a * ep_prev * m;
-            zM[(size_t)l * P + p] = m;
-            zE[(size_t)l * P + p] = ep;
-            if (l <= n - 3) {
-                gW += f * ep;
-                f = -a * ep;            // f_{l+1} = f_l cp_l = -a ep_l
-            }
-            cp_prev = cp;
-            ep_prev = ep;
-        }
         za[p] = a;
-        zW[p] = 1.0 / (B + gW + (f - a) * (cp + ep));       // f = f_{n-2}, cp / ep = those of row n-2
+        if (S == 1) {
+            periodic_tables(a, B, nlon, zM + p, zE + p, (size_t)P, &zW[p]);
+            continue;
+        }
+        double unused;
+        periodic_tables(a, B, m, zM + p, zE + p, (size_t)P, &unused);      // the open chain's m_l, ep_l are the same recurrences
+        double alpha = 0.0;
+        for (int i = 0; i <= m - 2; ++i) alpha += (i == 0 ? 1.0 : zE[(size_t)(i - 1) * P + p]) * zE[(size_t)i * P + p];
+        const double cp_last = a * zM[(size_t)(m - 2) * P + p], ep_last = zE[(size_t)(m - 2) * P + p];
+        const double a2 = a * ep_last, B2 = B - a * cp_last - a * alpha;
+        za2[p] = a2;
+        periodic_tables(a2, B2, S, rM + p, rE + p, (size_t)P, &zW[p]);
     }
     HIPCHK(hipStreamSynchronize(main_stream(h)));
     if (h->ztab) (void)hipFree(h->ztab);
     h->ztab = nullptr;
     h->nlon = 0;
-    HIPCHK(hipMalloc(&h->ztab, sizeof(double) * tab.size()));
+    HIPCHK(hipMalloc(&h->ztab, sizeof(double) * (tab.size() + scratch)));
     HIPCHK(hipMemcpy(h->ztab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+    h->zM = h->ztab; h->zE = h->zM + chain_rows * P; h->zrM = h->zE + chain_rows * P; h->zrE = h->zrM + red_rows * P;
+    h->za = h->zrE + red_rows * P; h->za2 = h->za + P; h->zW = h->za2 + P;
+    h->zsu = h->zW + P; h->zsg = h->zsu + scratch / 3; h->zsy = h->zsg + scratch / 3;
     h->nlon = nlon;
+    h->zseg = S;
     return EBM_OK;
 }
 hipError_t zonal_sweep(ebm_ctx *h, const double *T, double *outZ, double *outU) {
-    const size_t nP = (size_t)h->nlon * (size_t)h->pitch;
-    return ebm::launch_zonal_sweep(T, outZ, outU, h->ztab, h->ztab + nP, h->ztab + 2 * nP, h->ztab + 2 * nP + h->pitch,
-                                   h->nlon, h->ncol / h->nlon, (int)h->pitch, h->p.cw / h->dt, main_stream(h));
+    const int nmember = h->ncol / h->nlon;
+    const double rtheta = h->p.cw / h->dt;
+    if (h->zseg == 1)
+        return ebm::launch_zonal_sweep(T, outZ, outU, h->zM, h->zE, h->za, h->zW, h->nlon, nmember, (int)h->pitch, rtheta,
+                                       main_stream(h));
+    return ebm::launch_zonal_sweep_segmented(T, outZ, outU, h->zM, h->zE, h->zrM, h->zrE, h->za, h->za2, h->zW, h->zsu, h->zsg,
+                                             h->zsy, h->nlon, h->zseg, nmember, (int)h->pitch, rtheta, main_stream(h));
 }
 
 ebm::StepArgs base_args(const ebm_ctx *h) {

@@ -187,7 +187,8 @@ int ebm_diffusion(ebm_handle_t h, const double *temp, const double *base, double
  * (1 - x^2 is evaluated as (1 - x)(1 + x), which does not cancel near the pole) and form the zonal heat-flux convergence
  *     Z_l = (U_l - temp_l) cw/dt      ( = D/((1-x_k^2) dlambda^2) (U_{l-1} - 2 U_l + U_{l+1}) ).
  * THIS TEXT IS THE DEFINITION.  The solve is free arithmetic (its result is defined by the linear system, like T0's): one
- * lane per (member, latitude) walks the longitudes, so every access is along the contiguous latitude axis.
+ * lane per (member, latitude) walks the longitudes, so every access is along the contiguous latitude axis; circles of 256
+ * longitudes and more are cut into 4 ... 32 segments (a function of nlon only) with a reduced periodic system of their ends.
  * temp, out_U, out_Z: [ncol][nlat] host arrays (either output may be NULL); nlon >= 3 must divide ncol.  MIZ-family
  * handles.  Synchronous.
  * Why this is an operator and not a model: coupling it to the column step by operator splitting (Z of the previous step's

@@ -1,7 +1,8 @@
 """GPU tests (-m gpu) of ebm_zonal_diffusion — the zonal partner of the meridional diffusion operator as a backward-Euler
 substep (an EXTENSION defined in include/ebm_hip.h; not in the reference: "parity unpinned" by
-construction).  The HIP kernel (one lane per latitude walking the longitudes, periodic Thomas carrying the last unknown)
-is held to the checker's two restatements — which use two other algorithms (Fourier diagonalisation; Thomas +
+construction).  The HIP kernels (one lane per latitude walking the longitudes, periodic Thomas carrying the last unknown;
+circles of 256 longitudes and more cut into 4 ... 32 segments with a reduced periodic system of the segment ends)
+are held to the checker's two restatements — which use two other algorithms (Fourier diagonalisation; Thomas +
 Sherman-Morrison) — and to closed forms that involve no restatement at all."""
 import numpy as np
 import pytest
@@ -19,8 +20,11 @@ def make_engine(pkg, st, ncol, **kw):
 @pytest.mark.parametrize("kind,nlat,nlon,nmember,nt,cells", [
     ("sin", 180, 3, 2, 2000, 4), ("sin", 180, 7, 1, 2000, 2),          # the shortest circles; both launch geometries
     ("identity", 255, 16, 3, 2000, 4),                                 # ragged meridian (pitch 256)
-    ("sin", 1000, 64, 2, 60000, 2), ("sin", 1024, 512, 2, 2000, 4),    # one rank's grid of BASELINE configs[4]: a up to 3e5 at the pole
+    ("sin", 1000, 64, 2, 60000, 2), ("sin", 1024, 512, 2, 2000, 4),    # one rank's grid of BASELINE configs[4]: a up to 3e5 at the pole; 8 segments
     ("sin", 4096, 64, 1, 2000, 4), ("sin", 2, 5, 1, 2000, 4),
+    ("sin", 180, 256, 2, 2000, 2), ("identity", 300, 320, 1, 2000, 4),   # circles cut into 4 segments (of 64 and 80 unknowns)
+    ("sin", 512, 2048, 1, 2000, 4),                                     # 32 segments of 64
+    ("sin", 96, 255, 1, 2000, 4),                                       # 255 longitudes: not divisible, one segment
 ])
 def test_zonal_substep_matches_both_restatements(pkg, oracle, coracle, kind, nlat, nlon, nmember, nt, cells):
     """U and Z against the NumPy (Fourier) and C (Sherman-Morrison) restatements of the header's definition, on random

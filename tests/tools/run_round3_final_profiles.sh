@@ -27,8 +27,13 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python tests/tools/pmc_summary.py $O/pmc_step_FETCH_SIZE "miz_step_kernel<4, 1, 1, 1024, false>" 3 > $O/pmc_step_summary.txt 2>&1
 python tests/tools/pmc_summary.py $O/pmc_step_WRITE_SIZE "miz_step_kernel<4, 1, 1, 1024, false>" 3 >> $O/pmc_step_summary.txt 2>&1
-python tests/tools/pmc_summary.py $O/pmc_zonal_FETCH_SIZE "zonal_sweep_kernel" 2 > $O/pmc_zonal_summary.txt 2>&1
-python tests/tools/pmc_summary.py $O/pmc_zonal_WRITE_SIZE "zonal_sweep_kernel" 2 >> $O/pmc_zonal_summary.txt 2>&1
+: > $O/pmc_zonal_summary.txt
+for K in zonal_seg_forward_kernel zonal_reduced_solve_kernel zonal_seg_backward_kernel; do
+  echo "# $K" >> $O/pmc_zonal_summary.txt
+  python tests/tools/pmc_summary.py $O/pmc_zonal_FETCH_SIZE "$K" 2 >> $O/pmc_zonal_summary.txt 2>&1
+  python tests/tools/pmc_summary.py $O/pmc_zonal_WRITE_SIZE "$K" 2 >> $O/pmc_zonal_summary.txt 2>&1
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_zonal_single -- python3 tests/tools/zonal_profile.py 1 4 4096 2048 > $O/prof_zonal_single.log 2>&1
 : > $O/other_workloads.jsonl
 for W in "miz_4096x2048 --launch-chains 2" "miz_4096x2048_step" "miz_4096x2048_step --launch-chains 2" \
          "miz_180x1 --steps 2000" "miz_180x1 --steps 2048 --steps-per-launch 64" "miz_180x1 --steps 2048 --steps-per-launch 1024" \

@@ -2,7 +2,7 @@
 """Repeated ebm_zonal_diffusion calls on one rank's grid of BASELINE configs[4] (32 members of 1024 x 512), for
 `rocprofv3 --kernel-trace --stats` (the kernel's time) and `--pmc FETCH_SIZE` / `WRITE_SIZE` passes:
 
-    rocprofv3 --kernel-trace --stats --output-format csv -d OUT -- python3 tests/tools/zonal_profile.py [nmember] [reps]
+    rocprofv3 --kernel-trace --stats --output-format csv -d OUT -- python3 tests/tools/zonal_profile.py [nmember] [reps] [nlat] [nlon]
 
 Prints the shape and the algorithmic bytes of one sweep (read temp, write the forward sweep's dp into Z's array, read it back,
 read temp again, write Z: 40 B per cell; the two coefficient tables, [nlon][nlat] each and shared by all members, come from
@@ -18,7 +18,8 @@ import __graft_entry__ as graft  # noqa: E402
 
 nmember = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-nlat, nlon = 1024, 512
+nlat = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+nlon = int(sys.argv[4]) if len(sys.argv) > 4 else 512
 pkg = graft.load_package()
 st = pkg.SpaceTime("sin", nlat, 2000, 1)
 par = pkg.default_parameters("MIZ")
