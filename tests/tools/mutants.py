@@ -91,10 +91,14 @@ MUTANTS = [
     ("zonal_last_row_coefficient_sign", "            f = -a * ee[i];", "            f = a * ee[i];"),
     ("zonal_back_substitution_drops_the_wrap_term", "const double U = __builtin_fma(a * mm[i], Un, __builtin_fma(ee[i], W, dd[i]));",
      "const double U = __builtin_fma(a * mm[i], Un, dd[i]);"),
-    ("zonal_coefficient_linear_in_dlambda", "a = theta * h->p.D / (m * (dl * dl));", "a = theta * h->p.D / (m * dl);", "ebm_runtime.hip"),
+    ("zonal_coefficient_linear_in_dlambda", "a = theta * h->p.D / (mm * (dl * dl));", "a = theta * h->p.D / (mm * dl);", "ebm_runtime.hip"),
     ("annual_means_all_from_the_first_variable", "const size_t base = (size_t)blockIdx.y * (size_t)var_stride + (size_t)col * (size_t)threads * cells;",
      "const size_t base = (size_t)col * (size_t)threads * cells;"),
-    ("ring_pieces_reuse_the_first_two_offsets", "const size_t r0 = i * rows_per;", "const size_t r0 = (i % 2) * rows_per;", "ebm_runtime.hip"),
+    ("ring_pieces_reuse_the_first_two_offsets", "const size_t r0 = i * rows_per;", "const size_t r0 = (i % 2) * rows_per;", "ebm_hostcopy.h"),
+    # (added after the zonal sweep was partitioned along the circle)
+    ("zonal_segment_end_takes_the_wrong_neighbour", "auto rhs = [&](int s_) { return __builtin_fma(a, su[o + (size_t)((s_ + 1) % S) * P], sg[o + (size_t)s_ * P]); };",
+     "auto rhs = [&](int s_) { return __builtin_fma(a, su[o + (size_t)s_ * P], sg[o + (size_t)s_ * P]); };"),
+    ("zonal_reduced_diagonal_without_the_spike_sum", "const double a2 = a * ep_last, B2 = B - a * cp_last - a * alpha;", "const double a2 = a * ep_last, B2 = B - a * cp_last;", "ebm_runtime.hip"),
     ("integrate_restarts_model_time", "f, diag, clock0 + tinx - 1,", "f, diag, tinx - 1,", "ebm_runtime.hip"),
     ("as_of_query_inverted", "    if (have != step)", "    if (have == step)", "ebm_runtime.hip"),
 ]
