@@ -832,6 +832,9 @@ __global__ void __launch_bounds__(TT, 4) miz_step_kernel(const StepArgs a) {
             increments(dif, dE, tbl, tbr);
 #pragma unroll
             for (int i = 0; i < C; ++i) {
+                // the explicit diffusion term waits in the Tw words of the stash (Tw is formed again below from the stashed
+                // Ew and phi — one division — instead of the whole stencil a second time)
+                sTw[i * T] = dif[i];
                 ra[i] = -(p.theta_imex * tlo[i]);
                 rc[i] = -(p.theta_imex * tup[i]);
                 rb[i] = 1.0 + p.theta_imex * (tlo[i] + tup[i]);
@@ -840,21 +843,30 @@ __global__ void __launch_bounds__(TT, 4) miz_step_kernel(const StepArgs a) {
         }
         __syncthreads();                                  // the solve's LDS reads are done before P0 is reused
         {
-            // Only Ti (xs) and the solution crossed the solve in registers: phi, x and Tbar are fetched /
-            // formed again (the lane's cell index made opaque, so that the reloads are real), the Tbar halo
-            // is exchanged again, and the explicit terms are evaluated a second time — same operands, same
+            // Only Ti (xs) and the solution crossed the solve in registers: phi and x are fetched again (the lane's cell
+            // index made opaque, so that the reloads are real), Tw and Tbar are formed again, the parked diffusion term comes
+            // back from the stash, and the explicit increment is evaluated a second time from it — same operands, same
             // operations, same bits — for the correction (dE_new - dE)/dt.
             unsigned kl = k0;
             asm volatile("" : "+v"(kl));
             load_chunk<C>(st + S_phi * a.fstride, kl, ph);
             load_chunk<C>(gX, kl, xk);
 #pragma unroll
-            for (int i = 0; i < C; ++i) tb[i] = xs[i] * ph[i] + (1.0 - ph[i]) * sTw[i * T];
-            double hl, hr, dE[C];
-            halo_exchange(P0, P0 + T, t, T, tb[0], tb[C - 1], hl, hr);
-            increments(difx, dE, hl, hr);
-#pragma unroll
-            for (int i = 0; i < C; ++i) difx[IMEX ? i : 0] = difx[IMEX ? i : 0] + div_with_rcp(sol[i] - dE[i], p.dt, p.rcp_dt);
+            for (int i = 0; i < C; ++i) {
+                const int k = (int)k0 + i;
+                const double dif0 = sTw[i * T];
+                const double tw = water_temperature(p, sEw[i * T], ph[i]);
+                sTw[i * T] = tw;                                      // the stash holds Tw again for the cell updates
+                tb[i] = xs[i] * ph[i] + (1.0 - ph[i]) * tw;
+                const double S = insolation(p, xk[i], ct);
+                const double L = p.A + p.B * (tb[i] - Tm);
+                const double sol_i = 0.0 + p.ai * S;
+                const double sol_w = 0.0 + (p.a0 - p.a2 * (xk[i] * xk[i])) * S;
+                const double Fvi = sol_i - L + dif0 + p.Fb + f;
+                const double Fvw = sol_w - L + dif0 + p.Fb + f;
+                const double dE = k < nlat ? (ph[i] * Fvi + (1.0 - ph[i]) * Fvw) * p.dt : 0.0;
+                difx[IMEX ? i : 0] = dif0 + div_with_rcp(sol[i] - dE, p.dt, p.rcp_dt);
+            }
         }
     }
     double *const park0 = P0 + 2 * T + t;                 // P0[2T..3T), P1[0..3T): clear of the halo words
