@@ -29,7 +29,7 @@ and the CPU baseline.  `ms_per_step` / `value` are the MEDIAN block; every block
 
 Other workloads (never the headline; `metric` names them):
   --workload miz_180x1 / miz_1440x1 [--steps-per-launch K]   1-D shapes of configs[0] / [1]; with K > 1
-        the fused-K path (ebm_run_fused: K steps per launch, state in registers), reported separately
+        the fused-K path (ebm_run_fused: K steps per launch, state in registers or LDS), reported separately
   --workload miz_1024x512x32_integrate   ebm_integrate with the annual-mean sums of all 10 solution
         variables taken from the step kernel's registers (savesol! fused; avg on, raw off)
   --workload miz_1024x512x32   the per-GPU share of BASELINE configs[4] (256 members of 1024 x 512 over 8 GPUs:
@@ -171,8 +171,11 @@ def kernel_name(model, K, info):
     """The kernel a workload's launches run, derived the way ebm_run_fused decides (csrc/ebm_runtime.hip)."""
     if not model.startswith("MIZ"):
         return "classic_step_kernel"
+    if K <= 1:
+        return "miz_step_kernel"
     fused_limit = 768 if info["cells_per_thread"] == 2 else 512
-    return "miz_fused_kernel" if (K > 1 and model == "MIZ" and info["threads"] <= fused_limit) else "miz_step_kernel"
+    # state in registers where it fits; resident in LDS for longer meridians and for the extension
+    return "miz_fused_kernel" if (model == "MIZ" and info["threads"] <= fused_limit) else "miz_resident_kernel"
 
 
 def main():
@@ -401,10 +404,11 @@ def main():
     kname = kernel_name(model, K, info)
     fused_note = None
     if spl > 1.0 and kname != "miz_step_kernel":
-        # K steps per launch with the state in registers: HBM is touched once per LAUNCH, so the algorithmic bytes per
+        # K steps per launch with the state on the chip: HBM is touched once per LAUNCH, so the algorithmic bytes per
         # cell-step are 1/K of the per-step figure; the kernel is bound by one workgroup's VALU issue and barrier chain
         bpc = bpc / spl
-        fused_note = ("fused-K: the state stays in registers between the steps of a launch; achieved/frac count the bytes "
+        where = "registers" if kname == "miz_fused_kernel" else "LDS"
+        fused_note = (f"fused-K: the state stays in {where} between the steps of a launch; achieved/frac count the bytes "
                       "really moved (per-step figure / K) — this kernel is VALU-issue and barrier-latency bound, not HBM bound")
     launches = cnt["launches"] / max(1, args.repeats)        # kernel launches per timed block
     ev_kernel_ms = max(ev_ms - (year_end_ms or 0.0), 1e-9)   # the step launches alone (integrate: without the year end)

@@ -46,8 +46,9 @@ enum OutMode {
     OUT_DIAG = 1,    // + T0 and the diagnostic fields
     OUT_SAVE = 2,    // savesol! fused into the step: annual-mean running sums and/or a raw snapshot
                      // from registers; the diagnostic fields only if write_diag
-    OUT_LOOP = 3,    // nfused steps in one launch, the whole state in registers between them (miz_fused_kernel: meridians of
-                     // up to 2048 cells; classic: any); the diagnostic fields after the last step if write_diag
+    OUT_LOOP = 3,    // nfused steps in one launch, the whole state on the chip between them (miz_fused_kernel: in registers,
+                     // meridians of up to 2048 cells; miz_resident_kernel: in LDS, longer ones and the extension; classic:
+                     // registers, any); the diagnostic fields after the last step if write_diag
 };
 
 // Per-latitude constant tables: one slab, table i at geom + i*gstride (gstride = pitch).
@@ -118,6 +119,9 @@ using KernelFn = void (*)(const StepArgs);
 KernelFn miz_step_kernels_identity(int cells, int mode, int threads);
 KernelFn miz_step_kernels_nonuniform(int cells, int mode, int threads);
 KernelFn miz_step_kernels_imex(int grid_kind, int mode, int threads);
+// fused-K with the state resident in LDS (miz_resident_kernel): four cells per thread; the reference's step beyond
+// kFusedRegThreads threads, the extension at every size
+KernelFn miz_resident_kernels(int grid_kind, int threads, bool imex);
 
 // `count` workgroups, stepping columns first ... first + count - 1
 hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, bool imex, int first, int count,

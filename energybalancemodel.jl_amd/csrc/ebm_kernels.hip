@@ -53,6 +53,9 @@
 #if !defined(EBM_PART) || EBM_PART == 3
 #define EBM_PART_IMEX 1
 #endif
+#if !defined(EBM_PART) || EBM_PART == 4
+#define EBM_PART_LOOP 1
+#endif
 
 namespace ebm {
 
@@ -231,6 +234,29 @@ __device__ __forceinline__ void halo_exchange(double *E0, double *E1, int t, int
     right = t + 1 < T ? r : 0.0;
 }
 
+// The same exchange for the kernel whose LDS holds the state: inside a wave through the lane crossbar, between waves
+// through 32 words of E (wave w: last value at E[w], first value at E[16 + w]; T <= 1024).
+__device__ __forceinline__ void halo_exchange_waves(double *E, int t, int T, double first, double last,
+                                                    double &left, double &right) {
+    const int lane = t & 63, w = t >> 6, nw = T >> 6;
+    // (ds_bpermute with the lane taken from t, not __shfl_up / __shfl_down: their own lane id is loop-invariant and
+    // would be kept in a register across the caller's step loop)
+    auto from_lane = [](int src_lane, double v) {
+        const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+        const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+        return __hiloint2double(hi, lo);
+    };
+    double l = from_lane((lane + 63) & 63, last), r = from_lane((lane + 1) & 63, first);
+    if (lane == 63) E[w] = last;
+    if (lane == 0) E[16 + w] = first;
+    __syncthreads();
+    const double pl = E[w > 0 ? w - 1 : 0], nr = E[16 + (w + 1 < nw ? w + 1 : w)];
+    if (lane == 0) l = w > 0 ? pl : 0.0;
+    if (lane == 63) r = w + 1 < nw ? nr : 0.0;
+    left = l;
+    right = r;
+}
+
 // ---- tridiagonal solve of one meridian, T threads x C rows -----------------------------------
 // Row k: a_k x_{k-1} + b_k x_k + c_k x_{k+1} = d_k.  Thread t owns rows t*C..t*C+C-1.
 //  1. Thomas-eliminate the C-1 leading rows of the chunk with the left interface value
@@ -254,7 +280,12 @@ constexpr int second_level_rows(int /*T*/) {
 #endif
 }
 
-template <int C, int R>
+//
+// COMPACT (miz_resident_kernel, whose LDS holds the state): the same arithmetic in 4T doubles instead of 6T — P0 = 3T,
+// P1 = T.  The chunk summaries go through P0 as well (one more barrier before the interface rows overwrite them), the
+// second level's summaries and the interface solution through P1, the reduction's two buffers through P0.  On entry
+// P0 must be free and P1 free after the first barrier inside; on exit P0 is free and P1 may still be read.
+template <int C, int R, bool COMPACT = false>
 __device__ __forceinline__ void partition_solve_r(const double (&a)[C], const double (&b)[C],
                                                   const double (&c)[C], const double (&d)[C],
                                                   double (&x)[C], int t, int T, double *P0,
@@ -280,13 +311,14 @@ __device__ __forceinline__ void partition_solve_r(const double (&a)[C], const do
         v = __builtin_fma(-cp[i], v, lp[i]);
         wr = -cp[i] * wr;
     }
-    P1[t] = u;
-    P1[T + t] = v;
-    P1[2 * T + t] = wr;
+    double *const W1 = COMPACT ? P0 : P1;
+    W1[t] = u;
+    W1[T + t] = v;
+    W1[2 * T + t] = wr;
     __syncthreads();
     const bool has_next = t + 1 < T;
     const int tn = has_next ? t + 1 : t;
-    double un = P1[tn], vn = P1[T + tn], wn = P1[2 * T + tn];
+    double un = W1[tn], vn = W1[T + tn], wn = W1[2 * T + tn];
     un = has_next ? un : 0.0;
     vn = has_next ? vn : 0.0;
     wn = has_next ? wn : 0.0;
@@ -309,6 +341,7 @@ __device__ __forceinline__ void partition_solve_r(const double (&a)[C], const do
     // (row q of group g at [q*G + g]) so that both sides access consecutive words.
     const int G = T / R;
     const bool lvl2 = t < G;
+    if (COMPACT) __syncthreads();                         // the neighbours' summaries are read: P0 takes the rows
     {
         const int q = t % R, g = t / R;
         P0[q * G + g] = pa;
@@ -319,8 +352,10 @@ __device__ __forceinline__ void partition_solve_r(const double (&a)[C], const do
     double a2[R], c2[R], d2[R], cq[R - 1], dq[R - 1], lq[R - 1];
     // U is dead once every second-level thread has read its neighbour's entry, i.e. after the barrier that follows the
     // S0 writes: the reduction's second buffer reuses it, and P1's 3T doubles suffice for R = 2 as well (6G = 3T)
-    double *U = P1, *S0 = P1 + 3 * G, *S1 = P1;
+    double *U = P1, *S0 = COMPACT ? P0 : P1 + 3 * G, *S1 = COMPACT ? P0 + 3 * G : P1;
+    double *const Y = COMPACT ? P1 : P0;                  // the interface solution, row q of group g at [q*G + g]
     static_assert(R == 2 || R == 4 || R == 8, "second-level rows: P1 holds 6 T / R doubles");
+    static_assert(!COMPACT || R >= 4, "compact: the 3 T / R second-level summaries share P1's T doubles");
     if (lvl2) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
@@ -401,29 +436,29 @@ __device__ __forceinline__ void partition_solve_r(const double (&a)[C], const do
         const double L2raw = src[2 * G + (t > 0 ? t - 1 : 0)];
         const double L2 = t > 0 ? L2raw : 0.0;
         double y = qd;
-        P0[(R - 1) * G + t] = y;   // the level-1 rows in P0 were consumed before the barriers above
+        Y[(R - 1) * G + t] = y;   // the level-1 rows in P0 (compact: the summaries in P1) were consumed before the barriers above
 #pragma unroll
         for (int i = R - 2; i >= 0; --i) {
             y = __builtin_fma(-cq[i], y, __builtin_fma(lq[i], L2, dq[i]));
-            P0[i * G + t] = y;
+            Y[i * G + t] = y;
         }
     }
     __syncthreads();
-    pd = P0[(t % R) * G + t / R];
+    pd = Y[(t % R) * G + t / R];
     const int tm = t > 0 ? t - 1 : 0;
-    const double Lraw = P0[(tm % R) * G + tm / R];
+    const double Lraw = Y[(tm % R) * G + tm / R];
     const double L = t > 0 ? Lraw : 0.0;
     x[C - 1] = pd;
 #pragma unroll
     for (int i = C - 2; i >= 0; --i) x[i] = __builtin_fma(-cp[i], x[i + 1], __builtin_fma(lp[i], L, dp[i]));
 }
 // TT: the workgroup size if it is a compile-time constant (the MIZ kernels), 0 if only known at run time (classic)
-template <int C, int TT = 0>
+template <int C, int TT = 0, bool COMPACT = false>
 __device__ __forceinline__ void partition_solve(const double (&a)[C], const double (&b)[C],
                                                 const double (&c)[C], const double (&d)[C],
                                                 double (&x)[C], int t, int T, double *P0, double *P1) {
     // (run-time T: one copy of the solve only — two would take the classic K-step kernel past its 128 VGPRs)
-    partition_solve_r<C, second_level_rows(TT != 0 ? TT : 1024)>(a, b, c, d, x, t, T, P0, P1);
+    partition_solve_r<C, second_level_rows(TT != 0 ? TT : 1024), COMPACT>(a, b, c, d, x, t, T, P0, P1);
 }
 
 // ---- MIZ pointwise physics (one cell), bit-exact restatement of src/miz.jl:160-194 ----------
@@ -565,7 +600,9 @@ __device__ __forceinline__ double insolation(ConstParams &p, double xk, double c
 // T0 < Tm in cell i of this thread), tridiagonal solve, new active set; returns whether any thread's
 // set changed.  P0/P1 must be free on entry; on exit every thread has passed a barrier after its last
 // LDS access.
-template <int C, int TT>
+// COMPACT: P0 = 3T, P1 = T doubles (partition_solve_r); the halo goes through the lane crossbar and P1, the "any set
+// changed" vote through words of P0 that nothing writes before the next barrier — no static LDS.
+template <int C, int TT, bool COMPACT = false>
 __device__ __forceinline__ bool newton_iteration(const double (&lo)[C], const double (&up)[C],
                                                  const double (&dd)[C], const double (&ph)[C],
                                                  const double (&rd)[C], double (&xs)[C], unsigned &smask,
@@ -574,7 +611,8 @@ __device__ __forceinline__ bool newton_iteration(const double (&lo)[C], const do
 #pragma unroll
     for (int i = 0; i < C; ++i) g[i] = ((smask >> i) & 1u) ? ph[i] : 0.0;
     double gl, gr;
-    halo_exchange(P0, P0 + T, t, T, g[0], g[C - 1], gl, gr);
+    if constexpr (COMPACT) halo_exchange_waves(P1, t, T, g[0], g[C - 1], gl, gr);
+    else halo_exchange(P0, P0 + T, t, T, g[0], g[C - 1], gl, gr);
     double ra[C], rb[C], rc[C];
 #pragma unroll
     for (int i = 0; i < C; ++i) {
@@ -582,7 +620,7 @@ __device__ __forceinline__ bool newton_iteration(const double (&lo)[C], const do
         rc[i] = up[i] * (i < C - 1 ? g[i < C - 1 ? i + 1 : i] : gr);
         rb[i] = -__builtin_fma(lo[i] + up[i], g[i], dd[i]);
     }
-    partition_solve<C, TT>(ra, rb, rc, rd, xs, t, T, P0, P1);
+    partition_solve<C, TT, COMPACT>(ra, rb, rc, rd, xs, t, T, P0, P1);
     unsigned snew = 0;
 #pragma unroll
     for (int i = 0; i < C; ++i) snew |= (xs[i] < 0.0) ? (1u << i) : 0u;
@@ -590,7 +628,21 @@ __device__ __forceinline__ bool newton_iteration(const double (&lo)[C], const do
     snew &= nvalid >= C ? ~0u : (nvalid > 0 ? (1u << nvalid) - 1u : 0u);
     const int changed = snew != smask;
     smask = snew;
-    return __syncthreads_or(changed) != 0;
+    if constexpr (COMPACT) {
+        // one word per wave in the last third of P0: free here (the reduction's buffers were read before the solve's
+        // last barrier) and next written — by a solve's chunk summaries — only after a halo exchange's barrier
+        static_assert(TT > 0 && TT % 64 == 0, "whole waves");
+        int *const F = reinterpret_cast<int *>(P0 + 2 * T);
+        const bool wave_changed = __builtin_amdgcn_ballot_w64(changed != 0) != 0;
+        if ((t & 63) == 0) F[t >> 6] = wave_changed ? 1 : 0;
+        __syncthreads();
+        int any = 0;
+#pragma unroll
+        for (int w = 0; w < TT / 64; ++w) any |= F[w];
+        return any != 0;
+    } else {
+        return __syncthreads_or(changed) != 0;
+    }
 }
 
 // ---- savesol! from registers (src/infrastructure.jl:549-591) -----------------------------------
@@ -1133,6 +1185,318 @@ __global__ void __launch_bounds__(TT) miz_fused_kernel(const StepArgs a) {
         if (nfail) atomicAdd(cnt + 1, (unsigned long long)nfail);
     }
 }
+
+// Fused-K MIZ stepping for the meridians the register kernel above cannot hold (more than kFusedRegThreads threads
+// at four cells per thread: 2049 ... 4096 cells) and for the implicit-diffusion extension at every size: a.nfused steps
+// in one launch with the state RESIDENT IN LDS — Ei, Ew, h, D of every cell (cell i of thread t at i*T + t, 16 T doubles),
+// phi in registers.  What the per-step kernel spends its LDS on is cut to fit beside that: the solve runs in 4 T doubles
+// instead of 6 T (partition_solve_r<COMPACT>: one more barrier), the halo exchanges go through the lane crossbar and 32
+// words, the "any set changed" vote through words of the solve's buffer instead of the compiler's static LDS, and Tw is
+// formed again for the cell updates (one division) instead of being stashed: 20 T doubles = exactly the CU's 160 KiB at
+// T = 1024.  Global memory is touched at the start (state in), at the end (state out, diagnostics of the last step if
+// write_diag) and by the per-step table loads (L2 hits).  Every step performs the operations of miz_step_kernel in the
+// same order on the same values: bit-identical results (tests: test_resident_fused_run_equals_single_steps).
+template <int GRID, int TT, bool IMEX>
+__global__ void __launch_bounds__(TT) miz_resident_kernel(const StepArgs a) {
+    constexpr int C = 4, T = TT;
+    extern __shared__ double smem[];
+    const int t = threadIdx.x, col = a.col0 + (int)blockIdx.x;
+    const int nlat = a.nlat;
+    const unsigned k0 = (unsigned)t * C;
+    double *const PA = smem, *const PB = smem + 3 * T;    // the solve's 3T + T
+    // The state words: field F (Ei, Ew, h, D) of cell i of this thread at double (4 + 4F + i)*T + t.  A ds instruction
+    // reaches 64 KiB from its address register: one opaque base per 64 KiB window (three at T = 1024) and compile-time
+    // offsets, instead of one address register per word kept across the step loop.
+    typedef __attribute__((address_space(3))) double lds_double;
+    lds_double *win[3];
+    // (formed again at every phase that touches the state, from that phase's own copy of the thread index: three
+    // integer additions instead of three registers held across the solves)
+    auto windows = [&](int tx) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            win[j] = (lds_double *)smem + (j * 8192 + tx);
+            asm volatile("" : "+v"(win[j]));
+        }
+    };
+    windows(t);
+#define EBM_RES(F, i) win[((4 + 4 * (F) + (i)) * T) >> 13][((4 + 4 * (F) + (i)) * T) & 8191]
+#define sEi(i) EBM_RES(0, i)
+#define sEw(i) EBM_RES(1, i)
+#define sh(i) EBM_RES(2, i)
+#define sD(i) EBM_RES(3, i)
+    ConstParams &p = *reinterpret_cast<ConstParams *>(reinterpret_cast<uintptr_t>(a.p));
+    const double *const gX = a.geom + G_X * a.gstride;
+    double *const st = a.state + (size_t)col * (size_t)a.pitch;
+    const double Tm = p.Tm;
+    unsigned short *const cmask = a.amask + (size_t)col * T;           // wave-uniform
+    unsigned smask = cmask[t];
+    double ph[C];
+    {
+        double v[C];
+        load_chunk<C>(st + S_Ei * a.fstride, k0, v);
+#pragma unroll
+        for (int i = 0; i < C; ++i) sEi(i) = v[i];
+        load_chunk<C>(st + S_Ew * a.fstride, k0, v);
+#pragma unroll
+        for (int i = 0; i < C; ++i) sEw(i) = v[i];
+        load_chunk<C>(st + S_h * a.fstride, k0, v);
+#pragma unroll
+        for (int i = 0; i < C; ++i) sh(i) = v[i];
+        load_chunk<C>(st + S_D * a.fstride, k0, v);
+#pragma unroll
+        for (int i = 0; i < C; ++i) sD(i) = v[i];
+        load_chunk<C>(st + S_phi * a.fstride, k0, ph);
+    }
+    int nit = 0, nfail = 0;
+    const int nloop = a.nfused;
+    int ts = t;
+    for (int step = 0; step < nloop; ++step) {
+        // the step's scalars, read through the constant address space (the table is written by the host before the launch,
+        // never by a kernel): scalar loads into SGPRs — through the plain pointer they would be per-lane vector loads once
+        // the kernel has stored anything, and ct and f would occupy four VGPRs for the whole step
+        typedef const __attribute__((address_space(4))) StepSched ConstSched;
+        ConstSched &sc = *reinterpret_cast<ConstSched *>(reinterpret_cast<uintptr_t>(a.sched + (a.slot + step)));
+        const double ct = sc.ct;
+        // (the column's forcing is the same in every lane: moved to SGPRs — the column offset and schedule are read
+        // through plain pointers, i.e. by vector loads)
+        const double fv = column_forcing(a, col, sc.ft, sc.tyear);
+        const double f = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(fv)),
+                                          __builtin_amdgcn_readfirstlane(__double2loint(fv)));
+        const bool diag = a.write_diag && step == nloop - 1;
+        // The thread index is made opaque once per step: everything derived from it — the solve's neighbour rows at every
+        // level of the reduction, the transposed interface slots — is formed again in the step (a handful of integer
+        // operations) instead of being hoisted out of the step loop and kept in some thirty registers.
+        asm volatile("" : "+v"(ts));
+        const unsigned ks = (unsigned)ts * C;
+        // ---------------- phases A and B, as in miz_step_kernel ----------------
+        double rd[C], xs[C];
+        int it = 0;
+        bool again;
+        do {
+            double tlo[C], tup[C], dd[C];
+            // (the lane's cell index is made opaque at every group of table loads: the per-latitude tables are fetched
+            // again — L2 hits — through the wave-uniform base + 32-bit offset form, instead of living in registers, or
+            // their per-lane 64-bit addresses, across the solve and the steps)
+            unsigned kl = ks;
+            asm volatile("" : "+v"(kl));
+            windows(ts);
+            load_chunk<C>(a.geom + G_LO * a.gstride, kl, tlo);
+            load_chunk<C>(a.geom + G_UP * a.gstride, kl, tup);
+            if (it == 0) {
+                double xk[C], r[C];
+                load_chunk<C>(gX, kl, xk);
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    const double tw = water_temperature(p, sEw(i), ph[i]);
+                    dd[i] = t0_diag_excess(p, sh(i));
+                    r[i] = (1.0 - ph[i]) * (tw - Tm);
+                }
+                double rl, rr;
+                halo_exchange_waves(PB, ts, T, r[0], r[C - 1], rl, rr);
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    const double rm = i > 0 ? r[i > 0 ? i - 1 : 0] : rl;
+                    const double rp = i < C - 1 ? r[i < C - 1 ? i + 1 : i] : rr;
+                    rd[i] = t0_rhs(p, insolation(p, xk[i], ct), tlo[i], tup[i], rm, r[i], rp, f);
+                }
+                __syncthreads();                                  // the halo words are rewritten by the iteration
+            } else {
+#pragma unroll
+                for (int i = 0; i < C; ++i) dd[i] = t0_diag_excess(p, sh(i));
+            }
+            ++it;
+            again = newton_iteration<C, TT, true>(tlo, tup, dd, ph, rd, xs, smask, ts, T, ks, nlat, PA, PB);
+        } while (again && it < kMaxNewton);
+        nit += it;
+        nfail += again ? 1 : 0;
+        // ---------------- phase D ----------------
+        int td = ts;                                      // phase D's own copy: nothing index-derived crosses the solve
+        asm volatile("" : "+v"(td));
+        unsigned kl = (unsigned)td * C;
+        windows(td);
+        double xk[C];
+        load_chunk<C>(gX, kl, xk);
+        double xl = gX[kl > 0 ? kl - 1 : 0], xr = gX[kl + C];
+        double g0[GRID == 0 ? C : 1], g1[GRID == 0 ? C : 1], g2[GRID == 0 ? C : 1];
+        double tb[C];
+        {
+            double T0[C];
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                T0[i] = xs[i] + Tm;                                       // new warm start, :64
+                const double ti = jl_min(T0[i], Tm);                      // ice_temp, :31,65
+                xs[i] = (sh(i) == 0.0) ? 0.0 : ti;                    // Ti: zeroref!, :66
+                const double tw = water_temperature(p, sEw(i), ph[i]);  // the value phase A formed
+                tb[i] = xs[i] * ph[i] + (1.0 - ph[i]) * tw;               // Tbar, :21-26
+            }
+            if (diag) store_chunk<C>(st + S_T0 * a.fstride, T0, kl, nlat);
+        }
+        double tbl, tbr;
+        halo_exchange_waves(PB, td, T, tb[0], tb[C - 1], tbl, tbr);
+        double difx[IMEX ? C : 1];
+        if constexpr (IMEX) {
+            // the extension's second solve, as in miz_step_kernel; nothing is parked here (no LDS is left): the explicit
+            // increment is evaluated a second time after the solve — same operands, same operations, same bits
+            auto increments = [&](double (&dif)[C], double (&dE)[C]) {
+                double Fl_ = 0.0, xxl_ = 0.0;
+                if constexpr (GRID == 0) {
+                    unsigned kg = kl;
+                    asm volatile("" : "+v"(kg));
+                    load_chunk<C>(a.geom + G_LO * a.gstride, kg, g0);
+                    load_chunk<C>(a.geom + G_DI * a.gstride, kg, g1);
+                    load_chunk<C>(a.geom + G_UP * a.gstride, kg, g2);
+                }
+                if (GRID == 1) Fl_ = interface_flux((int)kl, nlat, xl, xk[0], tbl, tb[0], xxl_);
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    const int k = (int)kl + i;
+                    const double tbm = i > 0 ? tb[i > 0 ? i - 1 : 0] : tbl;
+                    const double tbp = i < C - 1 ? tb[i < C - 1 ? i + 1 : i] : tbr;
+                    const double xp = i < C - 1 ? xk[i < C - 1 ? i + 1 : i] : xr;
+                    if (GRID == 0) {
+                        dif[i] = diffusion_uniform(k, nlat, g0[GRID == 0 ? i : 0], g1[GRID == 0 ? i : 0],
+                                                   g2[GRID == 0 ? i : 0], tbm, tb[i], tbp);
+                    } else {
+                        double xxr;
+                        const double Fr = interface_flux(k + 1, nlat, xk[i], xp, tb[i], tbp, xxr);
+                        dif[i] = 0.0 + ieee_div(p.D * (Fr - Fl_), xxr - xxl_);               // :524
+                        Fl_ = Fr;
+                        xxl_ = xxr;
+                    }
+                    const double S = insolation(p, xk[i], ct);
+                    const double L = p.A + p.B * (tb[i] - Tm);
+                    const double sol_i = 0.0 + p.ai * S;
+                    const double sol_w = 0.0 + (p.a0 - p.a2 * (xk[i] * xk[i])) * S;
+                    const double Fvi = sol_i - L + dif[i] + p.Fb + f;
+                    const double Fvw = sol_w - L + dif[i] + p.Fb + f;
+                    dE[i] = k < nlat ? (ph[i] * Fvi + (1.0 - ph[i]) * Fvw) * p.dt : 0.0;     // padding rows stay decoupled
+                }
+            };
+            double sol[C];
+            {
+                double ra[C], rb[C], rc[C], dE[C], dif[C], tlo[C], tup[C];
+                load_chunk<C>(a.geom + G_LO * a.gstride, kl, tlo);
+                load_chunk<C>(a.geom + G_UP * a.gstride, kl, tup);
+                increments(dif, dE);
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    ra[i] = -(p.theta_imex * tlo[i]);
+                    rc[i] = -(p.theta_imex * tup[i]);
+                    rb[i] = 1.0 + p.theta_imex * (tlo[i] + tup[i]);
+                }
+                partition_solve<C, TT, true>(ra, rb, rc, dE, sol, ts, T, PA, PB);
+            }
+            __syncthreads();                                  // the solve's last LDS reads are done
+            {
+                // Only Ti (xs), phi, the two halo values of Tbar and the solution crossed the solve in registers: x is
+                // fetched again (the lane's cell index made opaque, so that the reloads are real), Tw and Tbar are formed
+                // again from the state words
+                int tq = ts;
+                asm volatile("" : "+v"(tq));
+                const unsigned kq = (unsigned)tq * C;
+                windows(tq);
+                load_chunk<C>(gX, kq, xk);
+                xl = gX[kq > 0 ? kq - 1 : 0];
+                xr = gX[kq + C];
+                kl = kq;
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    const double tw = water_temperature(p, sEw(i), ph[i]);
+                    tb[i] = xs[i] * ph[i] + (1.0 - ph[i]) * tw;
+                }
+                double dif[C], dE[C];
+                increments(dif, dE);
+#pragma unroll
+                for (int i = 0; i < C; ++i) difx[IMEX ? i : 0] = dif[i] + div_with_rcp(sol[i] - dE[i], p.dt, p.rcp_dt);
+            }
+        }
+        double Fl = 0.0, xxl = 0.0;
+        if (GRID == 1) Fl = interface_flux((int)kl, nlat, xl, xk[0], tbl, tb[0], xxl);
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            __builtin_amdgcn_sched_barrier(0);                         // one cell at a time: bounded live ranges
+            const int k = (int)kl + i;
+            const double tbm = i > 0 ? tb[i > 0 ? i - 1 : 0] : tbl;
+            const double tbp = i < C - 1 ? tb[i < C - 1 ? i + 1 : i] : tbr;
+            const double xp = i < C - 1 ? xk[i < C - 1 ? i + 1 : i] : xr;
+            const double S = insolation(p, xk[i], ct);
+            double dif;
+            if constexpr (IMEX) {
+                dif = difx[IMEX ? i : 0];
+            } else if (GRID == 0) {
+                // the three diagonals of the cell's pair arrive with its first cell (16-byte loads, L2 hits), not all
+                // twelve words before the loop
+                if ((i & 1) == 0) {
+                    const double2 q0 = *reinterpret_cast<const double2 *>(a.geom + G_LO * a.gstride + (kl + i));
+                    const double2 q1 = *reinterpret_cast<const double2 *>(a.geom + G_DI * a.gstride + (kl + i));
+                    const double2 q2 = *reinterpret_cast<const double2 *>(a.geom + G_UP * a.gstride + (kl + i));
+                    g0[GRID == 0 ? i : 0] = q0.x;  g0[GRID == 0 ? i + 1 : 0] = q0.y;
+                    g1[GRID == 0 ? i : 0] = q1.x;  g1[GRID == 0 ? i + 1 : 0] = q1.y;
+                    g2[GRID == 0 ? i : 0] = q2.x;  g2[GRID == 0 ? i + 1 : 0] = q2.y;
+                }
+                dif = diffusion_uniform(k, nlat, g0[GRID == 0 ? i : 0], g1[GRID == 0 ? i : 0], g2[GRID == 0 ? i : 0],
+                                        tbm, tb[i], tbp);
+            } else {
+                double xxr;
+                const double Fr = interface_flux(k + 1, nlat, xk[i], xp, tb[i], tbp, xxr);
+                dif = 0.0 + ieee_div(p.D * (Fr - Fl), xxr - xxl);         // :524
+                Fl = Fr;
+                xxl = xxr;
+            }
+            const double tw = water_temperature(p, sEw(i), ph[i]);      // and a third time: one division, no register
+            const MizCellOut o = miz_cell_update(p, f, S, xk[i], dif, tb[i], sEi(i), sEw(i), sh(i),
+                                                 sD(i), ph[i], tw, xs[i]);
+            const bool valid = k < nlat;                               // padding cells stay zero
+            sEi(i) = valid ? o.q[Q_Ei] : 0.0;
+            sEw(i) = valid ? o.q[Q_Ew] : 0.0;
+            sh(i) = valid ? o.q[Q_h] : 0.0;
+            sD(i) = valid ? o.q[Q_D] : 0.0;
+            ph[i] = valid ? o.q[Q_phi] : 0.0;
+            if (diag) {
+                // last step of the run only (wave-uniform base + the per-step opaque 32-bit cell index: no per-lane
+                // 64-bit addresses for the compiler to hoist out of the step loop and keep in registers)
+                (st + S_n * a.fstride)[kl + i] = valid ? o.q[Q_n] : 0.0;
+                (st + S_E * a.fstride)[kl + i] = valid ? o.q[Q_E] : 0.0;
+                (st + S_T * a.fstride)[kl + i] = valid ? o.q[Q_T] : 0.0;
+                (st + S_Ti * a.fstride)[kl + i] = valid ? o.q[Q_Ti] : 0.0;
+                (st + S_Tw * a.fstride)[kl + i] = valid ? o.q[Q_Tw] : 0.0;
+            }
+        }
+        __syncthreads();                                               // the halo words are rewritten by the next step
+    }
+    {
+        // (indices made opaque: the addresses are formed here, not kept — and spilled — across the step loop)
+        unsigned tl = (unsigned)ts;
+        asm volatile("" : "+v"(tl));
+        const unsigned ke = tl * C;
+        windows((int)tl);
+        double v[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[i] = sEi(i);
+        store_chunk<C>(st + S_Ei * a.fstride, v, ke, nlat);
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[i] = sEw(i);
+        store_chunk<C>(st + S_Ew * a.fstride, v, ke, nlat);
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[i] = sh(i);
+        store_chunk<C>(st + S_h * a.fstride, v, ke, nlat);
+#pragma unroll
+        for (int i = 0; i < C; ++i) v[i] = sD(i);
+        store_chunk<C>(st + S_D * a.fstride, v, ke, nlat);
+        store_chunk<C>(st + S_phi * a.fstride, ph, ke, nlat);
+        cmask[tl] = (unsigned short)smask;
+    }
+    if (ts == 0 && a.counters) {
+        unsigned long long *cnt = a.counters + 2 * (col % kCounterShards);
+        atomicAdd(cnt, (unsigned long long)nit);
+        if (nfail) atomicAdd(cnt + 1, (unsigned long long)nfail);
+    }
+}
+#undef sEi
+#undef sEw
+#undef sh
+#undef sD
+#undef EBM_RES
 
 // ---- classic (WE15) step, src/classic.jl:37-71 ------------------------------------------------
 // MODE: OUT_STATE (T, h written if write_diag), OUT_SAVE (savesol! from registers) or OUT_LOOP
@@ -1705,9 +2069,47 @@ KernelFn miz_step_kernels_imex(int grid_kind, int mode, int threads) {        //
 }
 #endif
 
+#ifdef EBM_PART_LOOP
+namespace {
+// the extension at every size; the reference's step where the register kernel ends (more than kFusedRegThreads threads)
+template <int GRID, bool IMEX>
+KernelFn miz_resident_for(int threads) {
+    switch (threads) {
+#define EBM_CASE(TT) case TT: return miz_resident_kernel<GRID, TT, IMEX>;
+#ifdef EBM_QUICK
+        EBM_CASE(1024)
+#else
+        EBM_CASE(576) EBM_CASE(640) EBM_CASE(704) EBM_CASE(768) EBM_CASE(832) EBM_CASE(896) EBM_CASE(960) EBM_CASE(1024)
+#endif
+        default: break;
+    }
+    if constexpr (IMEX) {
+        switch (threads) {
+#ifdef EBM_QUICK
+            EBM_CASE(64) EBM_CASE(256) EBM_CASE(512)
+#else
+            EBM_CASE(64) EBM_CASE(128) EBM_CASE(192) EBM_CASE(256) EBM_CASE(320) EBM_CASE(384) EBM_CASE(448) EBM_CASE(512)
+#endif
+            default: break;
+        }
+    }
+#undef EBM_CASE
+    return nullptr;
+}
+}  // namespace
+KernelFn miz_resident_kernels(int grid_kind, int threads, bool imex) {
+    if (imex) return grid_kind == 0 ? miz_resident_for<0, true>(threads) : miz_resident_for<1, true>(threads);
+    return grid_kind == 0 ? miz_resident_for<0, false>(threads) : miz_resident_for<1, false>(threads);
+}
+#endif
+
 #ifdef EBM_PART_MAIN
 namespace {
 
+// which fused-K kernel steps a shape (one rule for the kernel table, the LDS size and the attribute)
+bool fused_state_in_lds(int cells, int threads, bool imex) {
+    return imex || (cells == 4 && threads > kFusedRegThreads);
+}
 template <int C, int GRID>
 KernelFn miz_fused_for(int threads) {
     switch (threads) {
@@ -1726,8 +2128,8 @@ KernelFn miz_fused_for(int threads) {
     return nullptr;
 }
 KernelFn miz_kernel(int cells, int grid_kind, int mode, int threads, bool imex) {
-    if (mode == OUT_LOOP) {        // fused-K: not for the extension, not beyond kFusedRegThreads threads (nullptr)
-        if (imex) return nullptr;
+    if (mode == OUT_LOOP) {        // fused-K: state in registers where it fits, resident in LDS otherwise
+        if (fused_state_in_lds(cells, threads, imex)) return cells != 4 ? nullptr : miz_resident_kernels(grid_kind, threads, imex);
         if (cells == 2) return grid_kind == 0 ? miz_fused_for<2, 0>(threads) : miz_fused_for<2, 1>(threads);
         return grid_kind == 0 ? miz_fused_for<4, 0>(threads) : miz_fused_for<4, 1>(threads);
     }
@@ -1745,9 +2147,10 @@ KernelFn classic_kernel_c(int mode) {
     }
 }
 KernelFn classic_kernel(int cells, int mode) { return cells == 2 ? classic_kernel_c<2>(mode) : classic_kernel_c<4>(mode); }
-// LDS of a launch: the fused register kernel only needs the solve's buffers
-size_t miz_lds_bytes(const LaunchCfg &cfg, int mode) {
-    if (mode == OUT_LOOP) return sizeof(double) * 6 * (size_t)cfg.threads;
+// LDS of a launch: the fused register kernel only needs the solve's buffers; the resident kernel 4T for the solve and
+// 4 fields x 4 cells x T for the state
+size_t miz_lds_bytes(const LaunchCfg &cfg, int mode, bool imex) {
+    if (mode == OUT_LOOP) return sizeof(double) * (fused_state_in_lds(cfg.cells, cfg.threads, imex) ? 20 : 6) * (size_t)cfg.threads;
     return cfg.lds_bytes;
 }
 
@@ -1755,9 +2158,8 @@ size_t miz_lds_bytes(const LaunchCfg &cfg, int mode) {
 
 // Dynamic LDS above the 64 KiB default must be requested per kernel.
 hipError_t prepare_kernels(const LaunchCfg &cfg) {
-    if (cfg.lds_bytes <= 64 * 1024) return hipSuccess;
-    for (int grid = 0; grid < 2; ++grid)
-        for (int mode = OUT_STATE; mode <= OUT_SAVE; ++mode) {       // the fused kernel needs 6T doubles <= 24 KiB
+    for (int grid = 0; grid < 2 && cfg.lds_bytes > 64 * 1024; ++grid)
+        for (int mode = OUT_STATE; mode <= OUT_SAVE; ++mode) {       // the fused register kernel needs 6T doubles <= 24 KiB
             for (int imex = 0; imex < (cfg.cells == 4 ? 2 : 1); ++imex) {
                 KernelFn fn = miz_kernel(cfg.cells, grid, mode, cfg.threads, imex != 0);
                 if (!fn) return hipErrorInvalidValue;
@@ -1766,6 +2168,19 @@ hipError_t prepare_kernels(const LaunchCfg &cfg) {
                 if (e != hipSuccess) return e;
             }
         }
+    // the resident fused-K kernels: 160 T bytes
+    for (int imex = 0; imex < (cfg.cells == 4 ? 2 : 1); ++imex) {
+        if (!fused_state_in_lds(cfg.cells, cfg.threads, imex != 0)) continue;
+        const size_t bytes = miz_lds_bytes(cfg, OUT_LOOP, imex != 0);
+        if (bytes <= 64 * 1024) continue;
+        for (int grid = 0; grid < 2; ++grid) {
+            KernelFn fn = miz_kernel(cfg.cells, grid, OUT_LOOP, cfg.threads, imex != 0);
+            if (!fn) return hipErrorInvalidValue;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)bytes);
+            if (e != hipSuccess) return e;
+        }
+    }
     return hipSuccess;
 }
 
@@ -1775,7 +2190,7 @@ hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const Lau
     if (!fn || first < 0 || count < 1 || first + count > a.ncol) return hipErrorInvalidValue;
     StepArgs b = a;
     b.col0 = first;
-    fn<<<dim3(count), dim3(cfg.threads), miz_lds_bytes(cfg, mode), s>>>(b);
+    fn<<<dim3(count), dim3(cfg.threads), miz_lds_bytes(cfg, mode, imex), s>>>(b);
     return hipGetLastError();
 }
 

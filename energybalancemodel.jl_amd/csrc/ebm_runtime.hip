@@ -982,10 +982,9 @@ int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double
                   int steps_per_launch) {
     if (!h || nsteps < 0 || first_step < 0 || steps_per_launch < 1) return fail(EBM_ERR_ARG, "ebm_run_fused: bad argument");
     if (h->ttab.empty()) return fail(EBM_ERR_ARG, "ebm_run_fused: call ebm_set_time_table first");
-    // the fused MIZ kernel keeps the whole state in registers: up to kFusedRegThreads threads per
-    // meridian (2048 cells at 4 per thread); longer meridians are stepped one launch per step
-    if (steps_per_launch == 1 || h->imex || (h->model == EBM_MODEL_MIZ && h->cfg.threads > (h->cfg.cells == 2 ? ebm::kFusedRegThreads2 : ebm::kFusedRegThreads)))
-        return ebm_run(h, first_step, nsteps, f_steps, diag_last);
+    // every shape has a fused-K kernel: the state in registers up to kFusedRegThreads threads per meridian (2048 cells at
+    // 4 per thread; kFusedRegThreads2 at 2 per thread), resident in LDS for longer meridians and for the extension
+    if (steps_per_launch == 1) return ebm_run(h, first_step, nsteps, f_steps, diag_last);
     HIPCHK(hipSetDevice(h->device));
     if (!h->fused_sched) HIPCHK(hipMalloc(&h->fused_sched, sizeof(ebm::StepSched) * kFusedTable));
     const long long nt = (long long)h->ttab.size();

@@ -44,8 +44,14 @@ def classic_init(pkg, st, par, ncol):
     ("identity", 1101, 2, 100000, 11),    # two cells per thread: 768 threads for 551 chunks
     ("sin", 1536, 2, 150000, 6),          # the longest meridian with two cells per thread
     ("identity", 1000, 2, 60000, 5),
-    ("sin", 2048, 3, 262144, 9),          # the largest meridian with a fused kernel (512 threads)
+    ("sin", 2048, 3, 262144, 9),          # the largest meridian whose state the register kernel holds (512 threads)
     ("sin", 2045, 2, 262144, 4),
+    ("sin", 2049, 2, 262144, 5),          # from here on the state is resident in LDS (miz_resident_kernel): 576 threads
+    ("identity", 2560, 3, 400000, 7),     # 640 threads
+    ("sin", 3300, 2, 700000, 4),          # 832 threads, ragged
+    ("identity", 3840, 2, 900000, 6),     # 960 threads
+    ("sin", 4096, 3, 1048576, 8),         # BASELINE's largest meridian: 1024 threads, every byte of the CU's LDS
+    ("identity", 4093, 2, 1048576, 3),
 ])
 def test_fused_run_equals_single_steps(pkg, kind, nlat, ncol, nt, K, cells):
     """K steps per launch against one launch per step: same operations on the same values, so every
@@ -122,21 +128,29 @@ def test_fused_run_classic(pkg, nlat, ncol, K, cells):
         assert np.array_equal(out[1][k], out[K][k], equal_nan=True), k
 
 
-def test_fused_run_long_meridians_fall_back_to_single_launches(pkg):
-    """Meridians of more than 2048 cells have no fused kernel (their state does not fit the register
-    file): ebm_run_fused then launches every step, as documented, with identical results."""
+def test_fused_run_long_meridians_keep_their_state_in_lds(pkg):
+    """Meridians of more than 2048 cells do not fit the register file: their fused-K kernel keeps the state in LDS
+    (160 KiB at 4096 cells).  One launch per K steps — not one per step, as up to round 3 — and the same bits,
+    also over a run long enough for the ice edge to move (active-set changes inside a launch) and with the two
+    launch chains of ``launch_chains = 2``."""
     st = pkg.SpaceTime("sin", 4096, 1048576, 1)
     par = pkg.default_parameters("MIZ")
-    out = {}
-    for K in (1, 16):
-        with make_engine(pkg, "MIZ", st, par, 2) as eng:
-            eng.set_column_forcing(np.array([-0.5, 0.5]))
+    out, cnt = {}, {}
+    for K, chains in ((1, 1), (16, 1), (64, 2)):
+        with pkg.Engine("MIZ", st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval), st.dt, 5, device=0,
+                        launch_chains=chains, use_graph=False) as eng:
+            eng.set_column_forcing(np.linspace(-2.0, 2.0, 5))
             eng.set_time_table(st.t)
-            eng.run(0, 40, None, True, steps_per_launch=K)
+            eng.run(0, 200, None, True, steps_per_launch=K)
             out[K] = eng.get_state(ALL)
-            assert eng.counters()["launches"] == 40
-    for k in ALL:
-        assert np.array_equal(out[1][k], out[16][k], equal_nan=True), k
+            cnt[K] = eng.counters()
+    assert cnt[1]["launches"] == 200 and cnt[16]["launches"] == 13 and cnt[64]["launches"] == 2 * 4
+    assert cnt[1]["solves"] > 200 * 5                          # some steps took more than one iteration
+    for K in (16, 64):
+        assert cnt[K]["solves"] == cnt[1]["solves"] and cnt[K]["cap_hits"] == 0
+        for k in ALL:
+            assert np.array_equal(out[1][k], out[K][k], equal_nan=True), (K, k)
+    assert np.any(out[1]["phi"] > 0)
 
 
 def test_fused_run_matches_oracle(pkg, coracle):

@@ -105,19 +105,49 @@ def test_imex_through_integrate_and_the_host_mirror(pkg, oracle):
     pkg.reset_step_state()
 
 
-def test_imex_fused_request_falls_back_and_c2_is_not_used(pkg):
-    """The extension has per-step kernels only (4 cells per thread): ebm_run_fused launches every step."""
-    st = pkg.SpaceTime("sin", 180, 2000, 1)
+@pytest.mark.parametrize("kind,nlat,ncol,nt,K", [
+    ("sin", 180, 1, 2000, 32),
+    ("identity", 180, 3, 2000, 7),
+    ("sin", 63, 2, 2000, 16),
+    ("sin", 1440, 2, 2000, 25),
+    ("identity", 2048, 2, 2000, 9),
+    ("sin", 2500, 2, 2000, 5),
+    ("sin", 4096, 3, 2000, 12),
+    ("identity", 4096, 2, 2000, 64),
+])
+def test_imex_fused_run_equals_single_steps(pkg, kind, nlat, ncol, nt, K):
+    """The extension's fused-K kernel (state resident in LDS, both solves per step inside the launch) against one
+    launch per step: every field bitwise equal — with a run length that is not a multiple of K, a start late in the
+    year, per-step and per-column forcing, state handed over between two fused calls, and the long steps' many
+    active-set changes."""
+    st = pkg.SpaceTime(kind, nlat, nt, 1)
     par = pkg.default_parameters("MIZ")
-    out = {}
-    for K in (1, 32):
-        with make_engine(pkg, st, par, 1) as eng:
+    nsteps = 3 * K + 5
+    first = nt - 2 * K
+    f_steps = 0.3 * np.sin(np.arange(nsteps) / 5.0)
+    fcol = np.linspace(-1.5, 1.5, ncol) if ncol > 1 else np.array([0.4])
+    out, cnt = {}, {}
+    for mode in ("single", "fused"):
+        with make_engine(pkg, st, par, ncol) as eng:
+            assert eng.launch_info()["cells_per_thread"] == 4
+            eng.set_column_forcing(fcol)
             eng.set_time_table(st.t)
-            eng.run(0, 64, None, True, steps_per_launch=K)
-            out[K] = eng.get_state(ALL)
-            assert eng.counters()["launches"] == 64 and eng.launch_info()["cells_per_thread"] == 4
+            eng.run(0, 300, None, False)                       # cooling from the zero state: ice forms in these steps
+            eng.reset_counters()
+            if mode == "single":
+                eng.run(first, nsteps, f_steps, True)
+            else:
+                half = K + 3
+                eng.run(first, half, f_steps[:half], False, steps_per_launch=K)
+                eng.run(first + half, nsteps - half, f_steps[half:], True, steps_per_launch=K)
+            out[mode] = eng.get_state(ALL)
+            cnt[mode] = eng.counters()
     for k in ALL:
-        assert np.array_equal(out[1][k], out[32][k], equal_nan=True), k
+        assert np.array_equal(out["single"][k], out["fused"][k], equal_nan=True), k
+    assert np.any(out["single"]["Ew"] != 0)
+    assert cnt["fused"]["solves"] == cnt["single"]["solves"] and cnt["fused"]["cap_hits"] == 0
+    assert cnt["single"]["launches"] == nsteps
+    assert cnt["fused"]["launches"] == -(-(K + 3) // K) + -(-(nsteps - K - 3) // K)
 
 
 @pytest.mark.parametrize("kind,nlat,ncol", [("identity", 256, 2), ("sin", 1024, 3), ("sin", 4096, 2)])
