@@ -21,11 +21,12 @@
 //                                       registers (annual-mean sums, raw snapshots); IMEX: the implicit-diffusion
 //                                       extension (one more tridiagonal solve per step, see include/ebm_hip.h)
 //   miz_fused_kernel<C, GRID, T>        K steps per launch, the whole state in registers (<= 512 threads; 768 with C = 2)
+//   miz_resident_kernel<GRID, T, IMEX>  K steps per launch, the state resident in LDS (more than 512 threads; the extension)
 //   classic_step_kernel<C, MODE>        WE15 model: single step / savesol! / K steps per launch
 //   diffusion_kernel<GRID>              the diffusion operator on its own (ebm_diffusion)
 //   finish_mean, hemispheric_mean, mask_from_t0, derive_params, divide: small helpers
 // C = cells per thread (4; 2 for a few short meridians), GRID = 0 identity / 1 any other grid, T =
-// workgroup size as a compile-time constant.  Every one of the 293 instantiations uses 0 bytes of scratch
+// workgroup size as a compile-time constant.  Every one of the 347 instantiations uses 0 bytes of scratch
 // (tests/tools/resource_usage.py).
 //
 // Arithmetic policy.  Everything outside the tridiagonal solves is a bit-exact restatement of
@@ -39,7 +40,7 @@
 
 // EBM_PART: csrc/Makefile compiles this file once per part, in parallel, and links the objects — the MIZ
 // step kernel alone has 246 instantiations.  1 = its instantiations on the identity grid, 2 = on every other
-// grid, 3 = the implicit-diffusion extension, 0 = all other kernels and the launchers.  Undefined: one
+// grid, 3 = the implicit-diffusion extension, 4 = the LDS-resident fused-K kernel, 0 = all other kernels and the launchers.  Undefined: one
 // translation unit with everything (tests/tools/resource_usage.py, A/B builds).
 #if !defined(EBM_PART) || EBM_PART == 0
 #define EBM_PART_MAIN 1

@@ -58,8 +58,7 @@ enum ebm_status {
  * matrix (zero-flux ends); assuming that the surface temperature follows the increment with the water's
  * heat capacity cw is an upper bound of the true response (heat that melts or grows ice changes no
  * temperature), which is what makes the scheme stable.  THIS TEXT IS THE DEFINITION.
- * Same fields, parameters and entry points as EBM_MODEL_MIZ; one launch per step (ebm_run_fused does not
- * fuse it). */
+ * Same fields, parameters and entry points as EBM_MODEL_MIZ, ebm_run_fused included. */
 enum ebm_model { EBM_MODEL_MIZ = 0, EBM_MODEL_CLASSIC = 1, EBM_MODEL_MIZ_IMEX = 2 };
 
 /* SpaceTime{identity} uses the sparse uniform-x operator (src/infrastructure.jl:495-497);
@@ -242,10 +241,11 @@ int ebm_run(ebm_handle_t h, long long first_step, int nsteps, const double *f_st
 
 /* The same nsteps steps with `steps_per_launch` (K) consecutive steps fused into one kernel launch:
  * the time loop of integrate (src/infrastructure.jl:630-634) for callers that need no per-step
- * output.  Between the steps of a launch the whole state stays in registers; the per-step scalars
- * come from a device table.  Results are bit-identical to ebm_run.  Meridians of more than 2048 cells
- * have no fused kernel: there K is ignored and every step is its own launch (ebm_get_counters
- * reports the launches actually made).  Asynchronous. */
+ * output.  Between the steps of a launch the whole state stays on the chip — in registers for
+ * meridians of up to 2048 cells, in LDS for longer ones and for EBM_MODEL_MIZ_IMEX; the per-step
+ * scalars come from a device table.  Results are bit-identical to ebm_run for every model and size
+ * (ebm_get_counters reports the launches actually made: ceil(nsteps / K), twice that with two launch
+ * chains).  Asynchronous. */
 int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double *f_steps,
                   int diag_last, int steps_per_launch);
 
