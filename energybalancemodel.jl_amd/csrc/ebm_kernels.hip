@@ -1263,7 +1263,7 @@ __global__ void __launch_bounds__(TT) miz_resident_kernel(const StepArgs a) {
         const double fv = column_forcing(a, col, sc.ft, sc.tyear);
         const double f = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(fv)),
                                           __builtin_amdgcn_readfirstlane(__double2loint(fv)));
-        const bool diag = a.write_diag && step == nloop - 1;
+        const bool diag = a.write_diag != 0 && step + 1 == nloop;
         // The thread index is made opaque once per step: everything derived from it — the solve's neighbour rows at every
         // level of the reduction, the transposed interface slots — is formed again in the step (a handful of integer
         // operations) instead of being hoisted out of the step loop and kept in some thirty registers.
@@ -1307,7 +1307,7 @@ __global__ void __launch_bounds__(TT) miz_resident_kernel(const StepArgs a) {
             }
             ++it;
             again = newton_iteration<C, TT, true>(tlo, tup, dd, ph, rd, xs, smask, ts, T, ks, nlat, PA, PB);
-        } while (again && it < kMaxNewton);
+        } while (it < kMaxNewton && again);
         nit += it;
         nfail += again ? 1 : 0;
         // ---------------- phase D ----------------
@@ -1375,15 +1375,15 @@ __global__ void __launch_bounds__(TT) miz_resident_kernel(const StepArgs a) {
             };
             double sol[C];
             {
-                double ra[C], rb[C], rc[C], dE[C], dif[C], tlo[C], tup[C];
-                load_chunk<C>(a.geom + G_LO * a.gstride, kl, tlo);
-                load_chunk<C>(a.geom + G_UP * a.gstride, kl, tup);
+                double ra[C], rb[C], rc[C], dE[C], dif[C], qlo[C], qup[C];
+                load_chunk<C>(a.geom + G_LO * a.gstride, kl, qlo);
+                load_chunk<C>(a.geom + G_UP * a.gstride, kl, qup);
                 increments(dif, dE);
 #pragma unroll
                 for (int i = 0; i < C; ++i) {
-                    ra[i] = -(p.theta_imex * tlo[i]);
-                    rc[i] = -(p.theta_imex * tup[i]);
-                    rb[i] = 1.0 + p.theta_imex * (tlo[i] + tup[i]);
+                    ra[i] = -(p.theta_imex * qlo[i]);
+                    rc[i] = -(p.theta_imex * qup[i]);
+                    rb[i] = 1.0 + p.theta_imex * (qlo[i] + qup[i]);
                 }
                 partition_solve<C, TT, true>(ra, rb, rc, dE, sol, ts, T, PA, PB);
             }

@@ -101,6 +101,20 @@ MUTANTS = [
     ("zonal_reduced_diagonal_without_the_spike_sum", "const double a2 = a * ep_last, B2 = B - a * cp_last - a * alpha;", "const double a2 = a * ep_last, B2 = B - a * cp_last;", "ebm_runtime.hip"),
     ("integrate_restarts_model_time", "f, diag, clock0 + tinx - 1,", "f, diag, tinx - 1,", "ebm_runtime.hip"),
     ("as_of_query_inverted", "    if (have != step)", "    if (have == step)", "ebm_runtime.hip"),
+    # seventh batch: the LDS-resident fused-K kernel, its compact solve, its halo exchange and its vote
+    ("resident_diagnostics_of_the_first_step", "const bool diag = a.write_diag != 0 && step + 1 == nloop;", "const bool diag = a.write_diag != 0 && step == 0;"),
+    ("resident_newton_stops_after_one_iteration", "} while (it < kMaxNewton && again);", "} while (false);"),
+    ("resident_extension_matrix_diagonal_sign", "rb[i] = 1.0 + p.theta_imex * (qlo[i] + qup[i]);", "rb[i] = 1.0 - p.theta_imex * (qlo[i] + qup[i]);"),
+    ("resident_floe_size_not_written_back", "            sD(i) = valid ? o.q[Q_D] : 0.0;\n", ""),
+    ("resident_vote_reads_only_the_first_wave", "for (int w = 0; w < TT / 64; ++w) any |= F[w];", "for (int w = 0; w < 1; ++w) any |= F[w];"),
+    ("wave_halo_takes_its_own_edge", "const double pl = E[w > 0 ? w - 1 : 0],", "const double pl = E[w],"),
+    # (two buffer-aliasing mutants of the compact solve were tried and are NOT in this list — the reduction's second buffer
+    # overlapping the first by a third, the interface solution written into the buffer the reduction is still read from: both
+    # are RACES between waves that resume from the same barrier within a few cycles of each other, both passed every test on
+    # the box, and no test can catch such a race deterministically (no GPU sanitizer on this pool).  The buffer plan is argued
+    # in the comments of partition_solve_r instead.  What a wrong buffer does deterministically is covered by the next one.)
+    ("compact_summaries_overrun_into_the_state", "double *const W1 = COMPACT ? P0 : P1;", "double *const W1 = P1;"),
+    ("resident_state_words_one_slot_low", "win[((4 + 4 * (F) + (i)) * T) >> 13][((4 + 4 * (F) + (i)) * T) & 8191]", "win[((3 + 4 * (F) + (i)) * T) >> 13][((3 + 4 * (F) + (i)) * T) & 8191]"),
 ]
 
 
