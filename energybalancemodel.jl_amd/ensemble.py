@@ -68,9 +68,13 @@ class EnsembleRun:
             self.engine.set_column_schedules(forcings)
         self.step_index = 0
 
-    def run(self, nsteps, forcing=None, diag_last=True, steps_per_launch=1):
-        """Advance ``nsteps`` steps; ``forcing`` is a Forcing or None.  One launch per step unless
-        ``steps_per_launch`` > 1 (fused stepping, same results)."""
+    def run(self, nsteps, forcing=None, diag_last=True, steps_per_launch=None):
+        """Advance ``nsteps`` steps; ``forcing`` is a Forcing or None.  Nothing leaves the device between the
+        steps of this call, so they are fused ``steps_per_launch`` to a launch (ebm_run_fused: the state stays in
+        registers or LDS, bit-identical to one launch per step for every model and size); default 64, 1 = one
+        launch per step (ebm_run)."""
+        if steps_per_launch is None:
+            steps_per_launch = 64
         f = None
         if forcing is not None:
             T = (np.arange(self.step_index, self.step_index + nsteps) + 0.5) * self.st.dt

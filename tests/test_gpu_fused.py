@@ -153,6 +153,27 @@ def test_fused_run_long_meridians_keep_their_state_in_lds(pkg):
     assert np.any(out[1]["phi"] > 0)
 
 
+def test_ensemble_run_fuses_by_default(pkg):
+    """EnsembleRun.run lets nothing leave the device between its steps, so it fuses them (64 to a launch) unless told
+    otherwise — same bits as one launch per step, a Forcing evaluated per step, for a short and a long meridian and
+    for the extension."""
+    for model, nlat, nt in (("MIZ", 180, 2000), ("MIZ", 3000, 600000), ("MIZ_IMEX", 1440, 2000)):
+        st = pkg.SpaceTime("sin", nlat, nt, 1)
+        par = pkg.default_parameters("MIZ")
+        init = {k: np.zeros((3, nlat)) for k in PROG}
+        forcing = pkg.Forcing(0.0, 2.0, 0.0, (0, 0), (2.0, -2.0)) if nt == 2000 else None
+        out, launches = {}, {}
+        for spl in (None, 1):
+            run = pkg.EnsembleRun(model, st, par, init, fcol=np.array([-1.0, 0.0, 1.0]))
+            run.run(150, forcing, steps_per_launch=spl)
+            out[spl] = run.engine.get_state(ALL)
+            launches[spl] = run.engine.counters()["launches"]
+            run.close()
+        assert launches[1] == 150 and launches[None] == 3, launches
+        for k in ALL:
+            assert np.array_equal(out[None][k], out[1][k], equal_nan=True), (model, nlat, k)
+
+
 def test_fused_run_matches_oracle(pkg, coracle):
     """The fused path against the oracle directly (not only against the per-step path)."""
     nlat, nt, nsteps = 1440, 131072, 60
