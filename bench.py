@@ -189,6 +189,9 @@ def main():
     ap.add_argument("--preroll", type=float, default=PREROLL_S,
                     help="seconds of untimed steps right before the warm-up (0 under a counter-collecting profiler)")
     ap.add_argument("--workload", default="miz_4096x2048", choices=sorted(WORKLOADS))
+    ap.add_argument("--integrate-steps-per-launch", type=int, default=None,
+                    help="ebm_options.integrate_steps_per_launch of the integrate workload (default: the library's 64; 1 = one "
+                         "launch per step)")
     ap.add_argument("--steps-per-launch", type=int, default=1,
                     help="K > 1: fused-K stepping (ebm_run_fused), reported as its own metric")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
@@ -257,7 +260,8 @@ def main():
     cells_opt = 2 if (ncol == 1 and nlat <= 1536 and model == "MIZ" and os.environ.get("EBM_CELLS_PER_THREAD") is None) else None
     eng = pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval),
                      st.dt, ncol, device=device, cells_per_thread=cells_opt,
-                     launch_chains=(chains if chains > 1 else None), use_graph=(False if chains > 1 else None))
+                     launch_chains=(chains if chains > 1 else None), use_graph=(False if chains > 1 else None),
+                     integrate_steps_per_launch=args.integrate_steps_per_launch)
     if model == "Classic":
         Ts = 30.0 - 45.0 * st.x ** 2
         E0 = np.where(Ts >= 0, par["cw"] * Ts, par["Lf"] * Ts / 7.5)
@@ -403,7 +407,16 @@ def main():
     spl = (cnt["steps"] / cnt["launches"]) if cnt["launches"] else 1.0
     kname = kernel_name(model, K, info)
     fused_note = None
-    if spl > 1.0 and kname != "miz_step_kernel":
+    if integrate and spl > 1.5:
+        # ebm_integrate fuses the steps that need only the running sums (all but the year's last here): the state stays in
+        # LDS between the steps of a launch, the sums' read-modify-write (16 B per saved variable) is the traffic left
+        kname = "miz_resident_kernel"
+        bpc = BYTES_PER_CELL_STEP / spl + 16.0 * nsaved
+        fused_note = ("ebm_integrate, fused: the state stays in LDS between the steps of a launch (its 96 B per cell-step are "
+                      "moved once per launch), the annual-mean sums are read and written every step (16 B per saved variable) — "
+                      "ALGORITHMIC bytes: a workgroup adds to the same 80 KiB of sums on every step of its launch, so most of "
+                      "that read-modify-write is served by L2, and achieved may exceed what HBM itself streams")
+    elif spl > 1.0 and kname != "miz_step_kernel":
         # K steps per launch with the state on the chip: HBM is touched once per LAUNCH, so the algorithmic bytes per
         # cell-step are 1/K of the per-step figure; the kernel is bound by one workgroup's VALU issue and barrier chain
         bpc = bpc / spl

@@ -49,6 +49,8 @@ enum OutMode {
     OUT_LOOP = 3,    // nfused steps in one launch, the whole state on the chip between them (miz_fused_kernel: in registers,
                      // meridians of up to 2048 cells; miz_resident_kernel: in LDS, longer ones and the extension; classic:
                      // registers, any); the diagnostic fields after the last step if write_diag
+    OUT_LOOP_SAVE = 4,   // OUT_LOOP with savesol!'s running sums taken from every step (miz_resident_kernel<SAVE>; four cells
+                         // per thread; ebm_integrate's stretches without snapshots)
 };
 
 // Per-latitude constant tables: one slab, table i at geom + i*gstride (gstride = pitch).
@@ -122,6 +124,7 @@ KernelFn miz_step_kernels_imex(int grid_kind, int mode, int threads);
 // fused-K with the state resident in LDS (miz_resident_kernel): four cells per thread; the reference's step beyond
 // kFusedRegThreads threads, the extension at every size
 KernelFn miz_resident_kernels(int grid_kind, int threads, bool imex);
+KernelFn miz_resident_save_kernels(int grid_kind, int threads, bool imex);   // ... with savesol!'s sums, every size
 
 // `count` workgroups, stepping columns first ... first + count - 1
 hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, bool imex, int first, int count,

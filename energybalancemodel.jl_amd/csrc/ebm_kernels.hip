@@ -26,7 +26,7 @@
 //   diffusion_kernel<GRID>              the diffusion operator on its own (ebm_diffusion)
 //   finish_mean, hemispheric_mean, mask_from_t0, derive_params, divide: small helpers
 // C = cells per thread (4; 2 for a few short meridians), GRID = 0 identity / 1 any other grid, T =
-// workgroup size as a compile-time constant.  Every one of the 347 instantiations uses 0 bytes of scratch
+// workgroup size as a compile-time constant.  Every one of the 411 instantiations uses 0 bytes of scratch
 // (tests/tools/resource_usage.py).
 //
 // Arithmetic policy.  Everything outside the tridiagonal solves is a bit-exact restatement of
@@ -40,7 +40,8 @@
 
 // EBM_PART: csrc/Makefile compiles this file once per part, in parallel, and links the objects — the MIZ
 // step kernel alone has 246 instantiations.  1 = its instantiations on the identity grid, 2 = on every other
-// grid, 3 = the implicit-diffusion extension, 4 = the LDS-resident fused-K kernel, 0 = all other kernels and the launchers.  Undefined: one
+// grid, 3 = the implicit-diffusion extension, 4 = the LDS-resident fused-K kernel, 5 = the same with savesol!'s sums,
+// 0 = all other kernels and the launchers.  Undefined: one
 // translation unit with everything (tests/tools/resource_usage.py, A/B builds).
 #if !defined(EBM_PART) || EBM_PART == 0
 #define EBM_PART_MAIN 1
@@ -56,6 +57,9 @@
 #endif
 #if !defined(EBM_PART) || EBM_PART == 4
 #define EBM_PART_LOOP 1
+#endif
+#if !defined(EBM_PART) || EBM_PART == 5
+#define EBM_PART_LOOPSAVE 1
 #endif
 
 namespace ebm {
@@ -1197,8 +1201,13 @@ __global__ void __launch_bounds__(TT) miz_fused_kernel(const StepArgs a) {
 // T = 1024.  Global memory is touched at the start (state in), at the end (state out, diagnostics of the last step if
 // write_diag) and by the per-step table loads (L2 hits).  Every step performs the operations of miz_step_kernel in the
 // same order on the same values: bit-identical results (tests: test_resident_fused_run_equals_single_steps).
-template <int GRID, int TT, bool IMEX>
-__global__ void __launch_bounds__(TT) miz_resident_kernel(const StepArgs a) {
+//
+// SAVE: savesol!'s annual-mean running sums taken from every step of the launch (save_pair, as in miz_step_kernel<OUT_SAVE>:
+// the same per-cell sum in step order, the same bits) — what ebm_integrate launches for the stretches of a year that need
+// nothing else (no raw snapshot, no seasonal snapshot).  At four waves per SIMD for every workgroup size: this variant is
+// bound by the sums' read-modify-write traffic (16 B per saved variable and cell-step) and wants the occupancy.
+template <int GRID, int TT, bool IMEX, bool SAVE = false>
+__global__ void __launch_bounds__(TT, SAVE ? 4 : 1) miz_resident_kernel(const StepArgs a) {
     constexpr int C = 4, T = TT;
     extern __shared__ double smem[];
     const int t = threadIdx.x, col = a.col0 + (int)blockIdx.x;
@@ -1413,6 +1422,8 @@ __global__ void __launch_bounds__(TT) miz_resident_kernel(const StepArgs a) {
         }
         double Fl = 0.0, xxl = 0.0;
         if (GRID == 1) Fl = interface_flux((int)kl, nlat, xl, xk[0], tbl, tb[0], xxl);
+        [[maybe_unused]] MizCellOut o_even;                           // SAVE: the pair's first cell waits for its second
+        [[maybe_unused]] bool v_even = false;
 #pragma unroll
         for (int i = 0; i < C; ++i) {
             __builtin_amdgcn_sched_barrier(0);                         // one cell at a time: bounded live ranges
@@ -1461,6 +1472,15 @@ __global__ void __launch_bounds__(TT) miz_resident_kernel(const StepArgs a) {
                 (st + S_T * a.fstride)[kl + i] = valid ? o.q[Q_T] : 0.0;
                 (st + S_Ti * a.fstride)[kl + i] = valid ? o.q[Q_Ti] : 0.0;
                 (st + S_Tw * a.fstride)[kl + i] = valid ? o.q[Q_Tw] : 0.0;
+            }
+            if constexpr (SAVE) {
+                if ((i & 1) == 0) {
+                    o_even = o;
+                    v_even = valid;
+                } else {
+                    save_pair<Q_MIZ_COUNT>(a, (size_t)col * (size_t)a.pitch, (unsigned)((i / 2) * 2 * T) + 2u * (unsigned)td,
+                                           kl + (unsigned)(i - 1), o_even, o, v_even, valid);
+                }
             }
         }
         __syncthreads();                                               // the halo words are rewritten by the next step
@@ -2104,6 +2124,30 @@ KernelFn miz_resident_kernels(int grid_kind, int threads, bool imex) {
 }
 #endif
 
+#ifdef EBM_PART_LOOPSAVE
+namespace {
+template <int GRID, bool IMEX>
+KernelFn miz_resident_save_for(int threads) {              // every size: integrate has no other fused kernel
+    switch (threads) {
+#define EBM_CASE(TT) case TT: return miz_resident_kernel<GRID, TT, IMEX, true>;
+#ifdef EBM_QUICK
+        EBM_CASE(64) EBM_CASE(256) EBM_CASE(512) EBM_CASE(1024)
+#else
+        EBM_CASE(64) EBM_CASE(128) EBM_CASE(192) EBM_CASE(256) EBM_CASE(320) EBM_CASE(384) EBM_CASE(448) EBM_CASE(512)
+        EBM_CASE(576) EBM_CASE(640) EBM_CASE(704) EBM_CASE(768) EBM_CASE(832) EBM_CASE(896) EBM_CASE(960) EBM_CASE(1024)
+#endif
+        default: break;
+    }
+#undef EBM_CASE
+    return nullptr;
+}
+}  // namespace
+KernelFn miz_resident_save_kernels(int grid_kind, int threads, bool imex) {
+    if (imex) return grid_kind == 0 ? miz_resident_save_for<0, true>(threads) : miz_resident_save_for<1, true>(threads);
+    return grid_kind == 0 ? miz_resident_save_for<0, false>(threads) : miz_resident_save_for<1, false>(threads);
+}
+#endif
+
 #ifdef EBM_PART_MAIN
 namespace {
 
@@ -2129,6 +2173,7 @@ KernelFn miz_fused_for(int threads) {
     return nullptr;
 }
 KernelFn miz_kernel(int cells, int grid_kind, int mode, int threads, bool imex) {
+    if (mode == OUT_LOOP_SAVE) return cells != 4 ? nullptr : miz_resident_save_kernels(grid_kind, threads, imex);
     if (mode == OUT_LOOP) {        // fused-K: state in registers where it fits, resident in LDS otherwise
         if (fused_state_in_lds(cells, threads, imex)) return cells != 4 ? nullptr : miz_resident_kernels(grid_kind, threads, imex);
         if (cells == 2) return grid_kind == 0 ? miz_fused_for<2, 0>(threads) : miz_fused_for<2, 1>(threads);
@@ -2151,6 +2196,7 @@ KernelFn classic_kernel(int cells, int mode) { return cells == 2 ? classic_kerne
 // LDS of a launch: the fused register kernel only needs the solve's buffers; the resident kernel 4T for the solve and
 // 4 fields x 4 cells x T for the state
 size_t miz_lds_bytes(const LaunchCfg &cfg, int mode, bool imex) {
+    if (mode == OUT_LOOP_SAVE) return sizeof(double) * 20 * (size_t)cfg.threads;
     if (mode == OUT_LOOP) return sizeof(double) * (fused_state_in_lds(cfg.cells, cfg.threads, imex) ? 20 : 6) * (size_t)cfg.threads;
     return cfg.lds_bytes;
 }
@@ -2169,19 +2215,20 @@ hipError_t prepare_kernels(const LaunchCfg &cfg) {
                 if (e != hipSuccess) return e;
             }
         }
-    // the resident fused-K kernels: 160 T bytes
-    for (int imex = 0; imex < (cfg.cells == 4 ? 2 : 1); ++imex) {
-        if (!fused_state_in_lds(cfg.cells, cfg.threads, imex != 0)) continue;
-        const size_t bytes = miz_lds_bytes(cfg, OUT_LOOP, imex != 0);
-        if (bytes <= 64 * 1024) continue;
-        for (int grid = 0; grid < 2; ++grid) {
-            KernelFn fn = miz_kernel(cfg.cells, grid, OUT_LOOP, cfg.threads, imex != 0);
-            if (!fn) return hipErrorInvalidValue;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)bytes);
-            if (e != hipSuccess) return e;
+    // the resident fused-K kernels (and their savesol! variants, four cells per thread): 160 T bytes
+    for (int mode = OUT_LOOP; mode <= OUT_LOOP_SAVE; ++mode)
+        for (int imex = 0; imex < (cfg.cells == 4 ? 2 : 1); ++imex) {
+            if (mode == OUT_LOOP ? !fused_state_in_lds(cfg.cells, cfg.threads, imex != 0) : cfg.cells != 4) continue;
+            const size_t bytes = miz_lds_bytes(cfg, mode, imex != 0);
+            if (bytes <= 64 * 1024) continue;
+            for (int grid = 0; grid < 2; ++grid) {
+                KernelFn fn = miz_kernel(cfg.cells, grid, mode, cfg.threads, imex != 0);
+                if (!fn) return hipErrorInvalidValue;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)bytes);
+                if (e != hipSuccess) return e;
+            }
         }
-    }
     return hipSuccess;
 }
 

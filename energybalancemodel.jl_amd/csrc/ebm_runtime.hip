@@ -65,6 +65,7 @@ struct ebm_ctx {
     int prefetch = 0;                 // L2 prefetch distance of the MIZ kernel, columns (0 = off)
     double *hm_dev = nullptr;         // ebm_hemispheric_mean: per-column results on the device
     ebm::StepSched *fused_sched = nullptr;   // per-step scalars of the fused-K launches (kFusedTable entries)
+    int integrate_spl = 64;                  // ebm_options::integrate_steps_per_launch (1 = one launch per step)
     // hipGraph replay for launch-bound shapes (small grids): kGraphSteps step kernels per replay
     ebm::StepSched *sched_dev = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -546,6 +547,7 @@ int ebm_options_default(ebm_options *opt) {
     opt->use_graph = -1;
     opt->prefetch_cols = -1;
     opt->launch_chains = -1;
+    opt->integrate_steps_per_launch = -1;
     return EBM_OK;
 }
 
@@ -573,6 +575,8 @@ int ebm_create_ex(ebm_handle_t *out, int model, int grid, int nlat, int ncol, co
     if (opt.prefetch_cols < -1) return fail(EBM_ERR_ARG, "ebm_create_ex: prefetch_cols must be -1 (default), 0 or a distance");
     if (opt.launch_chains != -1 && opt.launch_chains != 1 && opt.launch_chains != 2)
         return fail(EBM_ERR_ARG, "ebm_create_ex: launch_chains must be -1 (default), 1 or 2");
+    if (opt.integrate_steps_per_launch < -1)
+        return fail(EBM_ERR_ARG, "ebm_create_ex: integrate_steps_per_launch must be -1 (default), 1 or a number of steps");
     if (model != EBM_MODEL_MIZ && model != EBM_MODEL_CLASSIC && model != EBM_MODEL_MIZ_IMEX)
         return fail(EBM_ERR_ARG, "ebm_create: unknown model");
     const bool imex = model == EBM_MODEL_MIZ_IMEX;        // the extension is the MIZ model with one more solve per step
@@ -598,6 +602,7 @@ int ebm_create_ex(ebm_handle_t *out, int model, int grid, int nlat, int ncol, co
     ebm_ctx *h = new ebm_ctx();
     h->model = model; h->grid = grid; h->nlat = nlat; h->ncol = ncol; h->device = device;
     h->dt = dt; h->cfg = cfg; h->imex = imex;
+    h->integrate_spl = opt.integrate_steps_per_launch <= 0 ? 64 : opt.integrate_steps_per_launch;
     for (int f = 0; f < EBM_F_COUNT; ++f) {
         h->written_epoch[f] = -1;
         h->written_step[f] = -1;
@@ -978,14 +983,12 @@ int ebm_run(ebm_handle_t h, long long first_step, int nsteps, const double *f_st
     return EBM_OK;
 }
 
-int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double *f_steps, int diag_last,
-                  int steps_per_launch) {
-    if (!h || nsteps < 0 || first_step < 0 || steps_per_launch < 1) return fail(EBM_ERR_ARG, "ebm_run_fused: bad argument");
-    if (h->ttab.empty()) return fail(EBM_ERR_ARG, "ebm_run_fused: call ebm_set_time_table first");
-    // every shape has a fused-K kernel: the state in registers up to kFusedRegThreads threads per meridian (2048 cells at
-    // 4 per thread; kFusedRegThreads2 at 2 per thread), resident in LDS for longer meridians and for the extension
-    if (steps_per_launch == 1) return ebm_run(h, first_step, nsteps, f_steps, diag_last);
-    HIPCHK(hipSetDevice(h->device));
+// nsteps steps, steps_per_launch to a launch, the per-step scalars from a device table: time-table entry tab_first + i and
+// model-time step clock_first + i for step i.  save: savesol!'s running sums from every step (OUT_LOOP_SAVE), else plain
+// fused stepping (OUT_LOOP).
+static int fused_range(ebm_ctx *h, long long tab_first, long long clock_first, int nsteps, const double *f_steps, int diag_last,
+                       int steps_per_launch, const SaveTarget *save) {
+    const long long first_step = clock_first;
     if (!h->fused_sched) HIPCHK(hipMalloc(&h->fused_sched, sizeof(ebm::StepSched) * kFusedTable));
     const long long nt = (long long)h->ttab.size();
     std::vector<ebm::StepSched> sched;
@@ -993,7 +996,7 @@ int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double
         const int n = std::min(kFusedTable, nsteps - s0);
         sched.resize(n);
         for (int i = 0; i < n; ++i) {
-            const long long ti = (first_step + s0 + i) % nt;
+            const long long ti = (tab_first + s0 + i) % nt;
             sched[i].ct = h->ttab[ti];
             sched[i].ct_next = h->ttab[(ti + 1) % nt];
             sched[i].ft = f_steps ? f_steps[s0 + i] : 0.0;
@@ -1009,7 +1012,12 @@ int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double
             a.nfused = std::min(steps_per_launch, n - i);
             a.prefetch = 0;
             a.write_diag = (diag_last && s0 + i + a.nfused == nsteps) ? 1 : 0;
-            hipError_t e = launch_step(h, a, ebm::OUT_LOOP);
+            if (save) {
+                a.sums = save->sums; a.sum_stride = save->sum_stride;
+                a.stage = nullptr;
+                std::memcpy(a.var_of, save->var_of, sizeof(a.var_of));
+            }
+            hipError_t e = launch_step(h, a, save ? ebm::OUT_LOOP_SAVE : ebm::OUT_LOOP);
             if (e != hipSuccess) return fail(EBM_ERR_HIP, std::string("fused launch: ") + hipGetErrorString(e));
             h->n_launches += h->split_col ? 2 : 1;
             note_steps(h, a.nfused, first_step + s0 + i + a.nfused - 1, a.write_diag != 0);
@@ -1019,6 +1027,17 @@ int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double
         h->clock = first_step + s0 + n;
     }
     return EBM_OK;
+}
+
+int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double *f_steps, int diag_last,
+                  int steps_per_launch) {
+    if (!h || nsteps < 0 || first_step < 0 || steps_per_launch < 1) return fail(EBM_ERR_ARG, "ebm_run_fused: bad argument");
+    if (h->ttab.empty()) return fail(EBM_ERR_ARG, "ebm_run_fused: call ebm_set_time_table first");
+    // every shape has a fused-K kernel: the state in registers up to kFusedRegThreads threads per meridian (2048 cells at
+    // 4 per thread; kFusedRegThreads2 at 2 per thread), resident in LDS for longer meridians and for the extension
+    if (steps_per_launch == 1) return ebm_run(h, first_step, nsteps, f_steps, diag_last);
+    HIPCHK(hipSetDevice(h->device));
+    return fused_range(h, first_step, first_step, nsteps, f_steps, diag_last, steps_per_launch, nullptr);
 }
 
 // integrate + savesol! (ebm_integrate) with, optionally, the per-column hemispheric means of the seasonal
@@ -1142,7 +1161,27 @@ static int integrate_impl(ebm_handle_t h, int nt, int dur, const double *f_steps
         half ^= 1;
         return e;
     };
+    // Stretches that need nothing but the running sums (no raw snapshot, no seasonal snapshot, not a year's last step, not the
+    // run's last step) are fused, integrate_spl steps to a launch, with the state resident on the chip
+    // (miz_resident_kernel<SAVE>; plain fused stepping when no mean is asked for): four cells per thread, MIZ / MIZ_IMEX.
+    const bool may_fuse = h->integrate_spl > 1 && h->model == EBM_MODEL_MIZ && h->cfg.cells == 4;
+    auto plain_step = [&](long long t) {
+        const long long ti_ = (t - 1) % nt + 1;
+        if (t >= total || ti_ == nt) return false;
+        if (stage && (!lastonly || t > total - nt)) return false;
+        if ((ti_ == winter_inx && (winter || hm_winter)) || (ti_ == summer_inx && (summer || hm_summer))) return false;
+        return true;
+    };
     for (long long tinx = 1; tinx <= total; ++tinx) {              // 1-based, as the reference
+        if (may_fuse && plain_step(tinx) && plain_step(tinx + 1)) {
+            long long n = 2;
+            while (n < (1 << 30) && plain_step(tinx + n)) ++n;
+            rc = fused_range(h, tinx - 1, clock0 + tinx - 1, (int)n, f_steps ? f_steps + (tinx - 1) : nullptr, 0, h->integrate_spl,
+                             sums ? &save : nullptr);
+            if (rc) { (void)cp->wait_all(); return rc; }
+            tinx += n - 1;
+            continue;
+        }
         const long long ti = (tinx - 1) % nt + 1;
         const long long year = (tinx - 1) / nt + 1;                // ceil(st.T[tinx])
         const double f = f_steps ? f_steps[tinx - 1] : 0.0;

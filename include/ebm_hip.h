@@ -118,13 +118,19 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
  *   are stepped by two independent chains of launches on two streams, which fill each other's launch boundaries and store
  *   tails: worth it where a CU holds a single workgroup (meridians of more than 2048 cells) and every chain still fills
  *   the chip several times over (4096 x 2048: 0.1656 -> 0.1594 ms per step).  Columns are independent: bit-identical either
- *   way.  ebm_get_counters counts one launch per chain and step; ignored with graph replay. */
+ *   way.  ebm_get_counters counts one launch per chain and step; ignored with graph replay.
+ * integrate_steps_per_launch: how ebm_integrate / ebm_integrate_hemispheric step through the stretches of a year that need
+ *   nothing but the annual-mean sums (no raw snapshot, no seasonal snapshot, not a year's last step): -1 (default) and
+ *   values > 1 = that many steps fused into one launch with the state resident on the chip and the sums taken from
+ *   every step (default 64); 1 = one launch per step everywhere.  Bit-identical either way.  Four cells per thread,
+ *   MIZ and MIZ_IMEX; other handles always step one launch at a time. */
 typedef struct ebm_options {
     int struct_bytes;
     int cells_per_thread;
     int use_graph;
     int prefetch_cols;
     int launch_chains;
+    int integrate_steps_per_launch;
 } ebm_options;
 int ebm_options_default(ebm_options *opt);
 /* ebm_create with explicit options (opt == NULL: the defaults, i.e. exactly ebm_create). */
@@ -256,8 +262,10 @@ int ebm_run_fused(ebm_handle_t h, long long first_step, int nsteps, const double
  *   winter, summer, avg  [nvars][dur][ncol][nlat]
  * winter_inx/summer_inx are the 1-based in-year indices st.winter.inx / st.summer.inx.
  * f_steps[nt*dur] as in ebm_run.  `fields` must be solution variables (not the hidden EBM_F_T0),
- * each at most once.  savesol! runs inside the step kernel: one launch per step, the annual-mean
- * sums and the raw snapshot are taken from the step's registers.  The annual mean is sum / nt with the sum
+ * each at most once.  savesol! runs inside the step kernel: the annual-mean sums and the raw snapshot are taken
+ * from the step's registers — one launch per step on the steps whose snapshot leaves the device (raw, winter,
+ * summer, a year's last step), ebm_options.integrate_steps_per_launch steps per launch in between, with the
+ * same bits.  The annual mean is sum / nt with the sum
  * taken per cell sequentially in step order; the reference's crossmean (src/utilities.jl:390-395) is
  * Statistics.mean over the year's snapshots, i.e. Julia's pairwise, SIMD-reassociated sum — the two agree up to
  * summation-order rounding (the parity tests hold avg to 1e-8 of the oracle's), not bit for bit.

@@ -254,6 +254,53 @@ def test_integrate_saves_from_registers(pkg, model, kind, nlat, ncol, nt, dur, c
         assert np.isnan(out["avg"][names.index("Ti")]).any()   # NaN sentinels propagate into the mean
 
 
+@pytest.mark.parametrize("model,kind,nlat,ncol,nt,dur,K", [
+    ("MIZ", "sin", 180, 3, 400, 3, 64),
+    ("MIZ", "identity", 180, 2, 300, 2, 7),
+    ("MIZ", "sin", 1024, 5, 250, 2, 64),
+    ("MIZ_IMEX", "sin", 1440, 2, 200, 3, 16),
+    ("MIZ", "sin", 2049, 2, 120, 2, 64),
+    ("MIZ", "identity", 4096, 3, 100, 2, 13),
+    ("MIZ_IMEX", "identity", 4096, 2, 80, 2, 64),
+])
+def test_integrate_fuses_the_stretches_between_snapshots(pkg, model, kind, nlat, ncol, nt, dur, K):
+    """ebm_integrate steps through what needs nothing but the annual-mean sums (lastonly: every year but the last, between
+    the seasonal snapshots) K steps to a launch with the state resident on the chip and the sums taken inside the launch
+    (miz_resident_kernel<SAVE>).  Against integrate_steps_per_launch = 1 (one launch per step everywhere): every output —
+    raw of the last year, winter, summer, the annual means of every year — and the final state bitwise equal, fewer
+    launches; also with no mean asked for (plain fused stepping) and with hemispheric means reduced on the device."""
+    st = pkg.SpaceTime(kind, nlat, nt, dur)
+    par = pkg.default_parameters("MIZ")
+    dt = st.dt if model == "MIZ_IMEX" else 1.0 / max(float(nt), 0.7 * nlat * nlat)
+    tt = (np.arange(nt) + 0.5) * dt
+    f_steps = 0.4 * np.sin(np.arange(nt * dur) / 9.0)
+    fcol = np.linspace(-1.0, 1.0, ncol)
+    out, launches, state = {}, {}, {}
+    for spl in (1, K):
+        with pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval), dt, ncol, device=0,
+                        integrate_steps_per_launch=spl) as eng:
+            eng.set_column_forcing(fcol)
+            eng.set_time_table(np.array([pkg.cos2pit(float(t)) for t in tt]))
+            eng.run(0, 30, None, False)
+            eng.reset_counters()
+            out[spl] = [eng.integrate(nt, dur, f_steps, True, 3, nt // 2 + 1, MIZ_VARS)]
+            launches[spl] = eng.counters()["launches"]
+            state[spl] = eng.get_state(ALL)
+            out[spl].append(eng.integrate(nt, dur, f_steps, True, 3, nt // 2 + 1, ("T", "phi"), want_avg=False))
+            out[spl].append(eng.integrate_hemispheric(nt, dur, f_steps, 3, nt // 2 + 1, ("T", "phi")))
+    assert launches[1] == nt * dur
+    segs = [2, nt // 2 + 1 - 3 - 1, nt - (nt // 2 + 1) - 1]        # plain steps before winter, between the seasons, before year end
+    per_year = sum(-(-n // K) if n >= 2 else n for n in segs) + 3
+    assert launches[K] == (dur - 1) * per_year + nt, (launches, per_year)
+    for a, b in zip(out[1], out[K]):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert (a[k] is None and b[k] is None) or np.array_equal(a[k], b[k], equal_nan=True), (model, nlat, k)
+    for k in ALL:
+        assert np.array_equal(state[1][k], state[K][k], equal_nan=True), k
+    assert np.ptp(out[1][0]["avg"][MIZ_VARS.index("T")][:, 0, 0]) > 0            # the years differ
+
+
 def test_integrate_avg_only_and_lastonly(pkg):
     """avg without seasonal snapshots or raw output (Engine.integrate(want_seasonal=False)): the sums
     run on every step, nothing else is stored; lastonly keeps the last year's raw snapshots only.

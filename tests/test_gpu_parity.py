@@ -1493,7 +1493,7 @@ def test_random_call_sequences_track_the_oracle(pkg, coracle, seed):
 
 @pytest.mark.parametrize("T", list(range(64, 1025, 64)))
 def test_every_workgroup_size(pkg, coracle, T, monkeypatch):
-    """Every workgroup size is its own set of kernel instantiations (328 of the library's 347): for each T = 64 ... 1024, both grid
+    """Every workgroup size is its own set of kernel instantiations (328 of the library's 411; the 64 savesol! variants of the resident kernel: test_integrate_fuses_the_stretches_between_snapshots): for each T = 64 ... 1024, both grid
     kinds, four cells per thread (nlat = 4T - 1, ragged) and two where that geometry exists (nlat = 2T - 1; T <= 512 and 768),
     the state-only, diagnostic and savesol! kernels, the fused-K kernel of the shape (state in registers, or resident in LDS
     beyond 512 threads and for the extension), the extension — 12 steps from a state with ice and open water against the
