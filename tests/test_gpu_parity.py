@@ -1493,11 +1493,11 @@ def test_random_call_sequences_track_the_oracle(pkg, coracle, seed):
 
 @pytest.mark.parametrize("T", list(range(64, 1025, 64)))
 def test_every_workgroup_size(pkg, coracle, T, monkeypatch):
-    """Every workgroup size is its own set of kernel instantiations (328 of the library's 411; the 64 savesol! variants of the resident kernel: test_integrate_fuses_the_stretches_between_snapshots): for each T = 64 ... 1024, both grid
+    """Every workgroup size is its own set of kernel instantiations (392 of the library's 411): for each T = 64 ... 1024, both grid
     kinds, four cells per thread (nlat = 4T - 1, ragged) and two where that geometry exists (nlat = 2T - 1; T <= 512 and 768),
     the state-only, diagnostic and savesol! kernels, the fused-K kernel of the shape (state in registers, or resident in LDS
-    beyond 512 threads and for the extension), the extension — 12 steps from a state with ice and open water against the
-    oracle, and the identities between the paths bitwise."""
+    beyond 512 threads and for the extension) and its savesol! variant, the extension — 12 steps from a state with ice and
+    open water against the oracle, and the identities between the paths bitwise."""
     nsteps, ncol = 12, 2
     fcol = np.array([-1.0, 1.5])
     for cells in (4, 2):
@@ -1520,19 +1520,25 @@ def test_every_workgroup_size(pkg, coracle, T, monkeypatch):
                 diag, ocnt = coracle.miz_run(kid, st.x, dict(par), dt, ct[30:30 + nsteps], np.zeros(nsteps), fcol, ref, imex=imex)
                 ref.update(diag)
                 got = {}
-                for how in ("run", "fused", "integrate"):
+                saved = {}
+                for how in ("run", "fused", "integrate", "integrate_fused"):
                     with pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval), dt, ncol, device=0) as eng:
                         info = eng.launch_info()
                         assert info["threads"] == T and info["cells_per_thread"] == cells, (info, T, cells)
                         eng.set_state(state)
                         eng.set_column_forcing(fcol)
-                        if how == "integrate":
+                        if how.startswith("integrate"):
+                            # with the raw snapshots every step is its own launch; without them the stretches between the
+                            # seasonal steps are fused (four cells per thread: the savesol! variant of the resident kernel)
                             eng.set_time_table(t64[30:30 + nsteps])
-                            out = eng.integrate(nsteps, 1, None, True, 5, 9, ("E", "T", "phi", "h"))
+                            out = eng.integrate(nsteps, 1, None, True, 5, 9, ("E", "T", "phi", "h"), want_raw=(how == "integrate"))
                             got[how] = eng.get_state(ALL)
+                            saved[how] = out
+                            assert eng.counters()["launches"] == (nsteps if (how == "integrate" or cells == 2) else 6), (how, eng.counters())
                             for vi, v in enumerate(("E", "T", "phi", "h")):
-                                assert np.array_equal(out["raw"][vi, -1], got[how][v], equal_nan=True), (T, cells, kind, model, v)
-                                assert np.array_equal(out["summer"][vi, 0], out["raw"][vi, 8], equal_nan=True)
+                                if how == "integrate":
+                                    assert np.array_equal(out["raw"][vi, -1], got[how][v], equal_nan=True), (T, cells, kind, model, v)
+                                    assert np.array_equal(out["summer"][vi, 0], out["raw"][vi, 8], equal_nan=True)
                         else:
                             eng.set_time_table(t64)
                             eng.run(30, nsteps, None, True, steps_per_launch=(5 if how == "fused" else 1))
@@ -1542,6 +1548,9 @@ def test_every_workgroup_size(pkg, coracle, T, monkeypatch):
                 for k in ALL:
                     assert np.array_equal(got["run"][k], got["fused"][k], equal_nan=True), (T, cells, kind, model, k)
                     assert np.array_equal(got["run"][k], got["integrate"][k], equal_nan=True), (T, cells, kind, model, k)
+                    assert np.array_equal(got["run"][k], got["integrate_fused"][k], equal_nan=True), (T, cells, kind, model, k)
+                for k in ("winter", "summer", "avg"):
+                    assert np.array_equal(saved["integrate"][k], saved["integrate_fused"][k], equal_nan=True), (T, cells, kind, model, k)
                 worst = max(scaled_err(got["run"][k], ref[k]) for k in ALL)
                 record_error(f"workgroup size {T}, {cells} cells per thread, {kind}, {model}: {nlat} cells, 12 steps", "all fields", worst, 1e-11)
                 assert worst <= 1e-11, (T, cells, kind, model, worst)         # measured: <= 6.5e-13 over all 82 combinations
