@@ -115,6 +115,12 @@ MUTANTS = [
     # in the comments of partition_solve_r instead.  What a wrong buffer does deterministically is covered by the next one.)
     ("compact_summaries_overrun_into_the_state", "double *const W1 = COMPACT ? P0 : P1;", "double *const W1 = P1;"),
     ("resident_state_words_one_slot_low", "win[((4 + 4 * (F) + (i)) * T) >> 13][((4 + 4 * (F) + (i)) * T) & 8191]", "win[((3 + 4 * (F) + (i)) * T) >> 13][((3 + 4 * (F) + (i)) * T) & 8191]"),
+    # eighth batch: ebm_integrate's fused stretches
+    ("resident_sums_of_the_second_pair_land_on_the_first", "(unsigned)((i / 2) * 2 * T) + 2u * (unsigned)td,", "2u * (unsigned)td,"),
+    ("integrate_fused_stretch_restarts_its_forcing", "(int)n, f_steps ? f_steps + (tinx - 1) : nullptr, 0, h->integrate_spl,", "(int)n, f_steps, 0, h->integrate_spl,", "ebm_runtime.hip"),
+    ("integrate_fused_stretch_one_table_entry_late", "rc = fused_range(h, tinx - 1, clock0 + tinx - 1,", "rc = fused_range(h, tinx, clock0 + tinx - 1,", "ebm_runtime.hip"),
+    ("integrate_fuses_through_the_winter_snapshot", "if ((ti_ == winter_inx && (winter || hm_winter)) || (ti_ == summer_inx && (summer || hm_summer))) return false;",
+     "if (ti_ == summer_inx && (summer || hm_summer)) return false;", "ebm_runtime.hip"),
 ]
 
 
