@@ -125,7 +125,9 @@ KernelFn miz_step_kernels_imex(int grid_kind, int mode, int threads);
 // kFusedRegThreads threads, the extension at every size
 KernelFn miz_resident_kernels(int grid_kind, int threads, bool imex);
 KernelFn miz_resident_save_kernels(int grid_kind, int threads, bool imex);   // ... with savesol!'s sums, every size
+KernelFn miz_fused2_save_kernels(int grid_kind, int threads);                // two cells per thread: miz_fused_kernel<2, ..., SAVE>
 
+bool has_miz_kernel(const LaunchCfg &cfg, int grid_kind, int mode, bool imex);   // is this (geometry, mode) compiled?
 // `count` workgroups, stepping columns first ... first + count - 1
 hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, bool imex, int first, int count,
                            hipStream_t s);

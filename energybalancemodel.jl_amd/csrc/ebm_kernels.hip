@@ -26,7 +26,7 @@
 //   diffusion_kernel<GRID>              the diffusion operator on its own (ebm_diffusion)
 //   finish_mean, hemispheric_mean, mask_from_t0, derive_params, divide: small helpers
 // C = cells per thread (4; 2 for a few short meridians), GRID = 0 identity / 1 any other grid, T =
-// workgroup size as a compile-time constant.  Every one of the 411 instantiations uses 0 bytes of scratch
+// workgroup size as a compile-time constant.  Every one of the 427 instantiations uses 0 bytes of scratch
 // (tests/tools/resource_usage.py).
 //
 // Arithmetic policy.  Everything outside the tridiagonal solves is a bit-exact restatement of
@@ -1058,8 +1058,11 @@ __global__ void __launch_bounds__(TT, 4) miz_step_kernel(const StepArgs a) {
 // the last step if write_diag) and by the scalar loads of the per-step table.  Every step performs the
 // operations of miz_step_kernel in the same order on the same values: bit-identical results
 // (tests: test_fused_run_equals_single_steps).
-template <int C, int GRID, int TT>
+// SAVE (two cells per thread only — what a caller asks for to run ONE short meridian): savesol!'s running sums from every
+// step of the launch, as in miz_resident_kernel<SAVE>; with two cells per thread the thread's chunk IS the pair.
+template <int C, int GRID, int TT, bool SAVE = false>
 __global__ void __launch_bounds__(TT) miz_fused_kernel(const StepArgs a) {
+    static_assert(!SAVE || C == 2, "the savesol! variant of the register kernel exists for two cells per thread");
     static_assert(C == 2 || C == 4, "cells per thread");
     constexpr int T = TT;
     extern __shared__ double smem[];
@@ -1142,6 +1145,8 @@ __global__ void __launch_bounds__(TT) miz_fused_kernel(const StepArgs a) {
         halo_exchange(P0, P0 + T, t, T, tb[0], tb[C - 1], tbl, tbr);
         double Fl = 0.0, xxl = 0.0;
         if (GRID == 1) Fl = interface_flux((int)k0, nlat, xl, xk[0], tbl, tb[0], xxl);
+        [[maybe_unused]] MizCellOut o_even;                            // SAVE: the pair's first cell waits for its second
+        [[maybe_unused]] bool v_even = false;
 #pragma unroll
         for (int i = 0; i < C; ++i) {
             __builtin_amdgcn_sched_barrier(0);                         // one cell at a time: bounded live ranges
@@ -1163,6 +1168,14 @@ __global__ void __launch_bounds__(TT) miz_fused_kernel(const StepArgs a) {
             const MizCellOut o = miz_cell_update(p, f, S, xk[i], dif, tb[i], Ei[i], Ew[i], hk[i], Dk[i], ph[i],
                                                  tw[i], xs[i]);
             const bool valid = k < nlat;                               // padding cells stay zero
+            if constexpr (SAVE) {
+                if (i == 0) {
+                    o_even = o;
+                    v_even = valid;
+                } else {
+                    save_pair<Q_MIZ_COUNT>(a, (size_t)col * (size_t)a.pitch, 2u * (unsigned)t, k0, o_even, o, v_even, valid);
+                }
+            }
             Ei[i] = valid ? o.q[Q_Ei] : 0.0;
             Ew[i] = valid ? o.q[Q_Ew] : 0.0;
             hk[i] = valid ? o.q[Q_h] : 0.0;
@@ -2146,6 +2159,25 @@ KernelFn miz_resident_save_kernels(int grid_kind, int threads, bool imex) {
     if (imex) return grid_kind == 0 ? miz_resident_save_for<0, true>(threads) : miz_resident_save_for<1, true>(threads);
     return grid_kind == 0 ? miz_resident_save_for<0, false>(threads) : miz_resident_save_for<1, false>(threads);
 }
+namespace {
+template <int GRID>
+KernelFn miz_fused2_save_for(int threads) {
+    switch (threads) {
+#define EBM_CASE(TT) case TT: return miz_fused_kernel<2, GRID, TT, true>;
+#ifdef EBM_QUICK
+        EBM_CASE(64) EBM_CASE(256) EBM_CASE(512)
+#else
+        EBM_CASE(64) EBM_CASE(128) EBM_CASE(192) EBM_CASE(256) EBM_CASE(320) EBM_CASE(384) EBM_CASE(448) EBM_CASE(512)
+#endif
+        default: break;       // (not 768 threads — meridians of 1025 ... 1536 cells: 144 B of scratch at its three waves per SIMD;
+    }                         //  ebm_integrate keeps one launch per step there)
+#undef EBM_CASE
+    return nullptr;
+}
+}  // namespace
+KernelFn miz_fused2_save_kernels(int grid_kind, int threads) {     // two cells per thread: the register kernel with the sums
+    return grid_kind == 0 ? miz_fused2_save_for<0>(threads) : miz_fused2_save_for<1>(threads);
+}
 #endif
 
 #ifdef EBM_PART_MAIN
@@ -2173,7 +2205,10 @@ KernelFn miz_fused_for(int threads) {
     return nullptr;
 }
 KernelFn miz_kernel(int cells, int grid_kind, int mode, int threads, bool imex) {
-    if (mode == OUT_LOOP_SAVE) return cells != 4 ? nullptr : miz_resident_save_kernels(grid_kind, threads, imex);
+    if (mode == OUT_LOOP_SAVE) {
+        if (cells == 4) return miz_resident_save_kernels(grid_kind, threads, imex);
+        return imex ? nullptr : miz_fused2_save_kernels(grid_kind, threads);
+    }
     if (mode == OUT_LOOP) {        // fused-K: state in registers where it fits, resident in LDS otherwise
         if (fused_state_in_lds(cells, threads, imex)) return cells != 4 ? nullptr : miz_resident_kernels(grid_kind, threads, imex);
         if (cells == 2) return grid_kind == 0 ? miz_fused_for<2, 0>(threads) : miz_fused_for<2, 1>(threads);
@@ -2196,7 +2231,7 @@ KernelFn classic_kernel(int cells, int mode) { return cells == 2 ? classic_kerne
 // LDS of a launch: the fused register kernel only needs the solve's buffers; the resident kernel 4T for the solve and
 // 4 fields x 4 cells x T for the state
 size_t miz_lds_bytes(const LaunchCfg &cfg, int mode, bool imex) {
-    if (mode == OUT_LOOP_SAVE) return sizeof(double) * 20 * (size_t)cfg.threads;
+    if (mode == OUT_LOOP_SAVE) return sizeof(double) * (cfg.cells == 4 ? 20 : 6) * (size_t)cfg.threads;
     if (mode == OUT_LOOP) return sizeof(double) * (fused_state_in_lds(cfg.cells, cfg.threads, imex) ? 20 : 6) * (size_t)cfg.threads;
     return cfg.lds_bytes;
 }
@@ -2218,7 +2253,7 @@ hipError_t prepare_kernels(const LaunchCfg &cfg) {
     // the resident fused-K kernels (and their savesol! variants, four cells per thread): 160 T bytes
     for (int mode = OUT_LOOP; mode <= OUT_LOOP_SAVE; ++mode)
         for (int imex = 0; imex < (cfg.cells == 4 ? 2 : 1); ++imex) {
-            if (mode == OUT_LOOP ? !fused_state_in_lds(cfg.cells, cfg.threads, imex != 0) : cfg.cells != 4) continue;
+            if (mode == OUT_LOOP ? !fused_state_in_lds(cfg.cells, cfg.threads, imex != 0) : cfg.cells != 4) continue;   // (6T otherwise)
             const size_t bytes = miz_lds_bytes(cfg, mode, imex != 0);
             if (bytes <= 64 * 1024) continue;
             for (int grid = 0; grid < 2; ++grid) {
@@ -2230,6 +2265,10 @@ hipError_t prepare_kernels(const LaunchCfg &cfg) {
             }
         }
     return hipSuccess;
+}
+
+bool has_miz_kernel(const LaunchCfg &cfg, int grid_kind, int mode, bool imex) {
+    return miz_kernel(cfg.cells, grid_kind, mode, cfg.threads, imex) != nullptr;
 }
 
 hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, bool imex, int first, int count,

@@ -1163,8 +1163,10 @@ static int integrate_impl(ebm_handle_t h, int nt, int dur, const double *f_steps
     };
     // Stretches that need nothing but the running sums (no raw snapshot, no seasonal snapshot, not a year's last step, not the
     // run's last step) are fused, integrate_spl steps to a launch, with the state resident on the chip
-    // (miz_resident_kernel<SAVE>; plain fused stepping when no mean is asked for): four cells per thread, MIZ / MIZ_IMEX.
-    const bool may_fuse = h->integrate_spl > 1 && h->model == EBM_MODEL_MIZ && h->cfg.cells == 4;
+    // (miz_resident_kernel<SAVE>, miz_fused_kernel<2, ..., SAVE>; plain fused stepping when no mean is asked for): MIZ and
+    // MIZ_IMEX, every geometry but two cells per thread at 768 threads.
+    const bool may_fuse = h->integrate_spl > 1 && h->model == EBM_MODEL_MIZ &&
+                          (!sums || ebm::has_miz_kernel(h->cfg, h->grid, ebm::OUT_LOOP_SAVE, h->imex));
     auto plain_step = [&](long long t) {
         const long long ti_ = (t - 1) % nt + 1;
         if (t >= total || ti_ == nt) return false;

@@ -122,8 +122,8 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
  * integrate_steps_per_launch: how ebm_integrate / ebm_integrate_hemispheric step through the stretches of a year that need
  *   nothing but the annual-mean sums (no raw snapshot, no seasonal snapshot, not a year's last step): -1 (default) and
  *   values > 1 = that many steps fused into one launch with the state resident on the chip and the sums taken from
- *   every step (default 64); 1 = one launch per step everywhere.  Bit-identical either way.  Four cells per thread,
- *   MIZ and MIZ_IMEX; other handles always step one launch at a time. */
+ *   every step (default 64); 1 = one launch per step everywhere.  Bit-identical either way.  MIZ and MIZ_IMEX (not two
+ *   cells per thread on meridians of more than 1024 cells); other handles always step one launch at a time. */
 typedef struct ebm_options {
     int struct_bytes;
     int cells_per_thread;

@@ -262,13 +262,17 @@ def test_integrate_saves_from_registers(pkg, model, kind, nlat, ncol, nt, dur, c
     ("MIZ", "sin", 2049, 2, 120, 2, 64),
     ("MIZ", "identity", 4096, 3, 100, 2, 13),
     ("MIZ_IMEX", "identity", 4096, 2, 80, 2, 64),
+    ("MIZ", "sin", 1300, 1, 90, 2, 64),        # two cells per thread at 768 threads has no fused variant: one launch per step
 ])
-def test_integrate_fuses_the_stretches_between_snapshots(pkg, model, kind, nlat, ncol, nt, dur, K):
+def test_integrate_fuses_the_stretches_between_snapshots(pkg, model, kind, nlat, ncol, nt, dur, K, cells):
     """ebm_integrate steps through what needs nothing but the annual-mean sums (lastonly: every year but the last, between
     the seasonal snapshots) K steps to a launch with the state resident on the chip and the sums taken inside the launch
-    (miz_resident_kernel<SAVE>).  Against integrate_steps_per_launch = 1 (one launch per step everywhere): every output —
+    (miz_resident_kernel<SAVE>; two cells per thread: miz_fused_kernel<2, ..., SAVE>).  Against
+    integrate_steps_per_launch = 1 (one launch per step everywhere): every output —
     raw of the last year, winter, summer, the annual means of every year — and the final state bitwise equal, fewer
     launches; also with no mean asked for (plain fused stepping) and with hemispheric means reduced on the device."""
+    if cells == 2 and nlat > 1536:
+        pytest.skip("two cells per thread exist up to 1536-cell meridians")
     st = pkg.SpaceTime(kind, nlat, nt, dur)
     par = pkg.default_parameters("MIZ")
     dt = st.dt if model == "MIZ_IMEX" else 1.0 / max(float(nt), 0.7 * nlat * nlat)
@@ -291,6 +295,8 @@ def test_integrate_fuses_the_stretches_between_snapshots(pkg, model, kind, nlat,
     assert launches[1] == nt * dur
     segs = [2, nt // 2 + 1 - 3 - 1, nt - (nt // 2 + 1) - 1]        # plain steps before winter, between the seasons, before year end
     per_year = sum(-(-n // K) if n >= 2 else n for n in segs) + 3
+    if cells == 2 and model == "MIZ" and nlat > 1024:
+        per_year = nt                                           # 768 threads, two cells each: not fused
     assert launches[K] == (dur - 1) * per_year + nt, (launches, per_year)
     for a, b in zip(out[1], out[K]):
         assert a.keys() == b.keys()

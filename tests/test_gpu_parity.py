@@ -1493,7 +1493,7 @@ def test_random_call_sequences_track_the_oracle(pkg, coracle, seed):
 
 @pytest.mark.parametrize("T", list(range(64, 1025, 64)))
 def test_every_workgroup_size(pkg, coracle, T, monkeypatch):
-    """Every workgroup size is its own set of kernel instantiations (392 of the library's 411): for each T = 64 ... 1024, both grid
+    """Every workgroup size is its own set of kernel instantiations (408 of the library's 427): for each T = 64 ... 1024, both grid
     kinds, four cells per thread (nlat = 4T - 1, ragged) and two where that geometry exists (nlat = 2T - 1; T <= 512 and 768),
     the state-only, diagnostic and savesol! kernels, the fused-K kernel of the shape (state in registers, or resident in LDS
     beyond 512 threads and for the extension) and its savesol! variant, the extension — 12 steps from a state with ice and
@@ -1529,12 +1529,13 @@ def test_every_workgroup_size(pkg, coracle, T, monkeypatch):
                         eng.set_column_forcing(fcol)
                         if how.startswith("integrate"):
                             # with the raw snapshots every step is its own launch; without them the stretches between the
-                            # seasonal steps are fused (four cells per thread: the savesol! variant of the resident kernel)
+                            # seasonal steps are fused (the savesol! variant of the resident kernel; of the register kernel with two
+                            # cells per thread, which does not exist at 768 threads)
                             eng.set_time_table(t64[30:30 + nsteps])
                             out = eng.integrate(nsteps, 1, None, True, 5, 9, ("E", "T", "phi", "h"), want_raw=(how == "integrate"))
                             got[how] = eng.get_state(ALL)
                             saved[how] = out
-                            assert eng.counters()["launches"] == (nsteps if (how == "integrate" or cells == 2) else 6), (how, eng.counters())
+                            assert eng.counters()["launches"] == (nsteps if (how == "integrate" or (cells == 2 and T == 768)) else 6), (how, eng.counters())
                             for vi, v in enumerate(("E", "T", "phi", "h")):
                                 if how == "integrate":
                                     assert np.array_equal(out["raw"][vi, -1], got[how][v], equal_nan=True), (T, cells, kind, model, v)
