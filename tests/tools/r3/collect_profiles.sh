@@ -9,6 +9,8 @@ cp "$(ks prof_headline)" profiles/r03_kernel_stats.csv
 cp "$(ks prof_step)" profiles/r03_step_diag_kernel_stats.csv
 cp $O/prof_step.json profiles/r03_bench_step_diag.json
 cp "$(ks prof_integrate)" profiles/r03_integrate_kernel_stats.csv
+cp "$(ks prof_integrate_fused)" profiles/r03_integrate_fused_kernel_stats.csv
+cp $O/docstring_example.log profiles/r03_docstring_example.log
 cp "$(ks prof_fused180)" profiles/r03_fused_180_kernel_stats.csv
 cp "$(ks prof_resident)" profiles/r03_resident_kernel_stats.csv
 cp $O/prof_resident.json profiles/r03_bench_resident.json

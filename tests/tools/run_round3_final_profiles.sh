@@ -13,7 +13,8 @@ set -e
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_headline -- python3 bench.py --cpu-budget 0 > $O/prof_headline.json 2> $O/prof_headline.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_step -- python3 bench.py --workload miz_4096x2048_step --cpu-budget 0 > $O/prof_step.json 2> $O/prof_step.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_integrate -- python3 bench.py --workload miz_1024x512x32_integrate --steps 200 --repeats 2 --cpu-budget 0 > $O/prof_integrate.json 2> $O/prof_integrate.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_integrate -- python3 bench.py --workload miz_1024x512x32_integrate --steps 200 --repeats 2 --cpu-budget 0 --integrate-steps-per-launch 1 > $O/prof_integrate.json 2> $O/prof_integrate.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_integrate_fused -- python3 bench.py --workload miz_1024x512x32_integrate --steps 256 --repeats 2 --cpu-budget 0 > $O/prof_integrate_fused.json 2> $O/prof_integrate_fused.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_fused180 -- python3 bench.py --workload miz_180x1 --steps 2048 --steps-per-launch 64 --cpu-budget 0 > $O/prof_fused180.json 2> $O/prof_fused180.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_resident -- python3 bench.py --workload miz_4096x2048 --steps 1024 --steps-per-launch 64 --cpu-budget 0 --repeats 2 > $O/prof_resident.json 2> $O/prof_resident.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_imex -- python3 bench.py --workload miz_imex_4096x2048 --cpu-budget 0 --repeats 2 > $O/prof_imex.json 2> $O/prof_imex.err
@@ -40,7 +41,8 @@ for W in "miz_4096x2048 --launch-chains 2" "miz_4096x2048_step" "miz_4096x2048_s
          "miz_180x1 --steps 2000" "miz_180x1 --steps 2048 --steps-per-launch 64" "miz_180x1 --steps 2048 --steps-per-launch 1024" \
          "miz_1440x1 --steps 2000" "miz_1440x1 --steps 2048 --steps-per-launch 64" \
          "miz_180x8192 --steps 512" "miz_180x8192 --steps 512 --steps-per-launch 64" \
-         "miz_1024x512x32" "miz_1024x512x32_integrate --steps 100 --repeats 3" "miz_2048x4096" \
+         "miz_1024x512x32" "miz_1024x512x32_integrate --steps 256 --repeats 3 --integrate-steps-per-launch 1" "miz_1024x512x32_integrate --steps 256 --repeats 3" \
+         "miz_1024x512x32_integrate --steps 1024 --repeats 3 --integrate-steps-per-launch 256" "miz_2048x4096" \
          "classic_1024x512 --steps 2000" "classic_1024x512 --steps 2048 --steps-per-launch 64" "miz_imex_4096x2048" "miz_imex_4096x2048 --launch-chains 2" \
          "miz_4096x2048 --steps-per-launch 16" "miz_4096x2048 --steps 1024 --steps-per-launch 64" "miz_4096x2048 --steps 1024 --steps-per-launch 256" \
          "miz_2048x4096 --steps 1024 --steps-per-launch 64" "miz_imex_4096x2048 --steps-per-launch 16" "miz_imex_4096x2048 --steps 1024 --steps-per-launch 64"; do
@@ -48,4 +50,5 @@ for W in "miz_4096x2048 --launch-chains 2" "miz_4096x2048_step" "miz_4096x2048_s
 done
 EBM_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload miz_1024x512x32 --steps 50 --cpu-budget 0 > $O/bench_two_ranks_one_gpu.log 2>&1
 python bench.py --gpus 2 --steps 20 --cpu-budget 0 > $O/bench_gpus2_refused.log 2>&1; echo "rc=$?" >> $O/bench_gpus2_refused.log
+python tests/tools/docstring_example.py > $O/docstring_example.log 2>&1
 tail -c 400 $O/bench_default.json
