@@ -2,7 +2,7 @@
 set -e
 cd "$(dirname "$0")/../../.."
 O=gpurun_out/r3final
-ks() { ls $O/$1/*/*_kernel_stats.csv | head -1; }
+ks() { ls -t $O/$1/*/*_kernel_stats.csv | head -1; }   # the newest: gpurun_out/ accumulates over calls
 cp $O/bench_default.json profiles/r03_bench.json
 cp $O/prof_headline.json profiles/r03_bench_under_rocprof.json
 cp "$(ks prof_headline)" profiles/r03_kernel_stats.csv
