@@ -167,15 +167,19 @@ def spawn_ranks(ngpus: int, argv: list) -> int:
     return proc.returncode
 
 
-def kernel_name(model, K, info):
-    """The kernel a workload's launches run, derived the way ebm_run_fused decides (csrc/ebm_runtime.hip)."""
+def kernel_name(model, K, info, ncol=1, ncu=256, fused_state=None):
+    """The kernel a workload's launches run, derived the way the library decides (csrc/ebm_kernels.hip: fused_state_in_lds;
+    csrc/ebm_runtime.hip: ebm_create_ex)."""
     if not model.startswith("MIZ"):
         return "classic_step_kernel"
     if K <= 1:
         return "miz_step_kernel"
-    fused_limit = 768 if info["cells_per_thread"] == 2 else 512
-    # state in registers where it fits; resident in LDS for longer meridians and for the extension
-    return "miz_fused_kernel" if (model == "MIZ" and info["threads"] <= fused_limit) else "miz_resident_kernel"
+    if info["cells_per_thread"] == 2:
+        return "miz_fused_kernel"
+    # four cells per thread: state in registers where that kernel exists and the launch has few columns; resident in LDS for
+    # longer meridians, for the extension, and for more columns than the register kernel runs in one round (unless told otherwise)
+    in_lds = fused_state if fused_state is not None else ncol > ncu * max(1, 256 // info["threads"])
+    return "miz_fused_kernel" if (model == "MIZ" and info["threads"] <= 512 and not in_lds) else "miz_resident_kernel"
 
 
 def main():
@@ -189,6 +193,8 @@ def main():
     ap.add_argument("--preroll", type=float, default=PREROLL_S,
                     help="seconds of untimed steps right before the warm-up (0 under a counter-collecting profiler)")
     ap.add_argument("--workload", default="miz_4096x2048", choices=sorted(WORKLOADS))
+    ap.add_argument("--fused-state", choices=("auto", "registers", "lds"), default="auto",
+                    help="ebm_options.fused_state_in_lds: where fused-K launches keep the state when both kernels exist")
     ap.add_argument("--integrate-steps-per-launch", type=int, default=None,
                     help="ebm_options.integrate_steps_per_launch of the integrate workload (default: the library's 64; 1 = one "
                          "launch per step)")
@@ -261,7 +267,8 @@ def main():
     eng = pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval),
                      st.dt, ncol, device=device, cells_per_thread=cells_opt,
                      launch_chains=(chains if chains > 1 else None), use_graph=(False if chains > 1 else None),
-                     integrate_steps_per_launch=args.integrate_steps_per_launch)
+                     integrate_steps_per_launch=args.integrate_steps_per_launch,
+                     fused_state_in_lds={"auto": None, "registers": False, "lds": True}[args.fused_state])
     if model == "Classic":
         Ts = 30.0 - 45.0 * st.x ** 2
         E0 = np.where(Ts >= 0, par["cw"] * Ts, par["Lf"] * Ts / 7.5)
@@ -405,7 +412,8 @@ def main():
     if every_step_diag:
         bpc += 48.0                                          # T0 and Tw, Ti, n, E, T written as well (144 B, SURVEY 8(d): 136 + T0)
     spl = (cnt["steps"] / cnt["launches"]) if cnt["launches"] else 1.0
-    kname = kernel_name(model, K, info)
+    kname = kernel_name(model, K, info, ncol, torch.cuda.get_device_properties(device).multi_processor_count,
+                        {"auto": None, "registers": False, "lds": True}[args.fused_state])
     fused_note = None
     if integrate and spl > 1.5:
         # ebm_integrate fuses the steps that need only the running sums (all but the year's last here): the state stays in

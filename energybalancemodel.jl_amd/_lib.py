@@ -42,7 +42,8 @@ STATUS = {0: "EBM_OK", -1: "EBM_ERR_ARG", -2: "EBM_ERR_HIP", -3: "EBM_ERR_UNSUPP
 class Options(C.Structure):
     """struct ebm_options (include/ebm_hip.h)."""
     _fields_ = [("struct_bytes", C.c_int), ("cells_per_thread", C.c_int), ("use_graph", C.c_int),
-                ("prefetch_cols", C.c_int), ("launch_chains", C.c_int), ("integrate_steps_per_launch", C.c_int)]
+                ("prefetch_cols", C.c_int), ("launch_chains", C.c_int), ("integrate_steps_per_launch", C.c_int),
+                ("fused_state_in_lds", C.c_int)]
 
 
 class EBMError(RuntimeError):

@@ -101,6 +101,11 @@ struct LaunchCfg {
     int threads;        // workgroup size (multiple of 64)
     int cells;          // cells per thread (C)
     size_t lds_bytes;   // dynamic LDS per workgroup
+    // fused-K launches of the reference's step where both kernels exist (four cells per thread, <= kFusedRegThreads threads):
+    // state resident in LDS (128 VGPRs: up to four workgroups per CU fill each other's barrier stalls — launches of many
+    // columns) instead of in registers (fewer LDS round trips: a few columns).  Same bits; set by the runtime, not by
+    // choose_launch — the GEOMETRY stays a function of (nlat, cells) only.
+    bool fused_in_lds;
 };
 
 constexpr int kCounterShards = 64;

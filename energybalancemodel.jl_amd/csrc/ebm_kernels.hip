@@ -26,7 +26,7 @@
 //   diffusion_kernel<GRID>              the diffusion operator on its own (ebm_diffusion)
 //   finish_mean, hemispheric_mean, mask_from_t0, derive_params, divide: small helpers
 // C = cells per thread (4; 2 for a few short meridians), GRID = 0 identity / 1 any other grid, T =
-// workgroup size as a compile-time constant.  Every one of the 427 instantiations uses 0 bytes of scratch
+// workgroup size as a compile-time constant.  Every one of the 443 instantiations uses 0 bytes of scratch
 // (tests/tools/resource_usage.py).
 //
 // Arithmetic policy.  Everything outside the tridiagonal solves is a bit-exact restatement of
@@ -1219,8 +1219,11 @@ __global__ void __launch_bounds__(TT) miz_fused_kernel(const StepArgs a) {
 // the same per-cell sum in step order, the same bits) — what ebm_integrate launches for the stretches of a year that need
 // nothing else (no raw snapshot, no seasonal snapshot).  At four waves per SIMD for every workgroup size: this variant is
 // bound by the sums' read-modify-write traffic (16 B per saved variable and cell-step) and wants the occupancy.
+// Up to 512 threads every variant is held to four waves per SIMD (128 VGPRs): there the kernel exists FOR its occupancy —
+// several workgroups per CU fill each other's barrier stalls (0.1278 -> 0.1121 ms per step on 2048 x 4096 against the
+// register kernel, 0.304 -> 0.209 on 1024 x 16384) — and is chosen for launches of many columns (LaunchCfg::fused_in_lds).
 template <int GRID, int TT, bool IMEX, bool SAVE = false>
-__global__ void __launch_bounds__(TT, SAVE ? 4 : 1) miz_resident_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(TT, (SAVE || TT <= 512) ? 4 : 1) miz_resident_kernel(const StepArgs a) {
     constexpr int C = 4, T = TT;
     extern __shared__ double smem[];
     const int t = threadIdx.x, col = a.col0 + (int)blockIdx.x;
@@ -2105,27 +2108,19 @@ KernelFn miz_step_kernels_imex(int grid_kind, int mode, int threads) {        //
 
 #ifdef EBM_PART_LOOP
 namespace {
-// the extension at every size; the reference's step where the register kernel ends (more than kFusedRegThreads threads)
+// every size for both models: the extension has no other fused kernel; the reference's step where the register kernel ends
+// (more than kFusedRegThreads threads) and, below that, where the handle prefers occupancy over latency
 template <int GRID, bool IMEX>
 KernelFn miz_resident_for(int threads) {
     switch (threads) {
 #define EBM_CASE(TT) case TT: return miz_resident_kernel<GRID, TT, IMEX>;
 #ifdef EBM_QUICK
-        EBM_CASE(1024)
+        EBM_CASE(64) EBM_CASE(256) EBM_CASE(512) EBM_CASE(1024)
 #else
+        EBM_CASE(64) EBM_CASE(128) EBM_CASE(192) EBM_CASE(256) EBM_CASE(320) EBM_CASE(384) EBM_CASE(448) EBM_CASE(512)
         EBM_CASE(576) EBM_CASE(640) EBM_CASE(704) EBM_CASE(768) EBM_CASE(832) EBM_CASE(896) EBM_CASE(960) EBM_CASE(1024)
 #endif
         default: break;
-    }
-    if constexpr (IMEX) {
-        switch (threads) {
-#ifdef EBM_QUICK
-            EBM_CASE(64) EBM_CASE(256) EBM_CASE(512)
-#else
-            EBM_CASE(64) EBM_CASE(128) EBM_CASE(192) EBM_CASE(256) EBM_CASE(320) EBM_CASE(384) EBM_CASE(448) EBM_CASE(512)
-#endif
-            default: break;
-        }
     }
 #undef EBM_CASE
     return nullptr;
@@ -2183,9 +2178,10 @@ KernelFn miz_fused2_save_kernels(int grid_kind, int threads) {     // two cells 
 #ifdef EBM_PART_MAIN
 namespace {
 
-// which fused-K kernel steps a shape (one rule for the kernel table, the LDS size and the attribute)
-bool fused_state_in_lds(int cells, int threads, bool imex) {
-    return imex || (cells == 4 && threads > kFusedRegThreads);
+// which fused-K kernel steps a handle's columns (one rule for the kernel table and the LDS size): the two compute the same
+// bits, so the choice is free to depend on the column count (LaunchCfg::fused_in_lds, set by the runtime)
+bool fused_state_in_lds(const LaunchCfg &cfg, bool imex) {
+    return imex || (cfg.cells == 4 && (cfg.threads > kFusedRegThreads || cfg.fused_in_lds));
 }
 template <int C, int GRID>
 KernelFn miz_fused_for(int threads) {
@@ -2204,13 +2200,14 @@ KernelFn miz_fused_for(int threads) {
 #undef EBM_CASE
     return nullptr;
 }
-KernelFn miz_kernel(int cells, int grid_kind, int mode, int threads, bool imex) {
+KernelFn miz_kernel(const LaunchCfg &cfg, int grid_kind, int mode, bool imex) {
+    const int cells = cfg.cells, threads = cfg.threads;
     if (mode == OUT_LOOP_SAVE) {
         if (cells == 4) return miz_resident_save_kernels(grid_kind, threads, imex);
         return imex ? nullptr : miz_fused2_save_kernels(grid_kind, threads);
     }
     if (mode == OUT_LOOP) {        // fused-K: state in registers where it fits, resident in LDS otherwise
-        if (fused_state_in_lds(cells, threads, imex)) return cells != 4 ? nullptr : miz_resident_kernels(grid_kind, threads, imex);
+        if (fused_state_in_lds(cfg, imex)) return cells != 4 ? nullptr : miz_resident_kernels(grid_kind, threads, imex);
         if (cells == 2) return grid_kind == 0 ? miz_fused_for<2, 0>(threads) : miz_fused_for<2, 1>(threads);
         return grid_kind == 0 ? miz_fused_for<4, 0>(threads) : miz_fused_for<4, 1>(threads);
     }
@@ -2232,7 +2229,7 @@ KernelFn classic_kernel(int cells, int mode) { return cells == 2 ? classic_kerne
 // 4 fields x 4 cells x T for the state
 size_t miz_lds_bytes(const LaunchCfg &cfg, int mode, bool imex) {
     if (mode == OUT_LOOP_SAVE) return sizeof(double) * (cfg.cells == 4 ? 20 : 6) * (size_t)cfg.threads;
-    if (mode == OUT_LOOP) return sizeof(double) * (fused_state_in_lds(cfg.cells, cfg.threads, imex) ? 20 : 6) * (size_t)cfg.threads;
+    if (mode == OUT_LOOP) return sizeof(double) * (fused_state_in_lds(cfg, imex) ? 20 : 6) * (size_t)cfg.threads;
     return cfg.lds_bytes;
 }
 
@@ -2240,40 +2237,34 @@ size_t miz_lds_bytes(const LaunchCfg &cfg, int mode, bool imex) {
 
 // Dynamic LDS above the 64 KiB default must be requested per kernel.
 hipError_t prepare_kernels(const LaunchCfg &cfg) {
-    for (int grid = 0; grid < 2 && cfg.lds_bytes > 64 * 1024; ++grid)
-        for (int mode = OUT_STATE; mode <= OUT_SAVE; ++mode) {       // the fused register kernel needs 6T doubles <= 24 KiB
-            for (int imex = 0; imex < (cfg.cells == 4 ? 2 : 1); ++imex) {
-                KernelFn fn = miz_kernel(cfg.cells, grid, mode, cfg.threads, imex != 0);
-                if (!fn) return hipErrorInvalidValue;
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds_bytes);
-                if (e != hipSuccess) return e;
-            }
-        }
-    // the resident fused-K kernels (and their savesol! variants, four cells per thread): 160 T bytes
-    for (int mode = OUT_LOOP; mode <= OUT_LOOP_SAVE; ++mode)
+    auto raise = [](KernelFn fn, size_t bytes) -> hipError_t {
+        if (!fn) return hipErrorInvalidValue;
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    };
+    for (int grid = 0; grid < 2; ++grid)
         for (int imex = 0; imex < (cfg.cells == 4 ? 2 : 1); ++imex) {
-            if (mode == OUT_LOOP ? !fused_state_in_lds(cfg.cells, cfg.threads, imex != 0) : cfg.cells != 4) continue;   // (6T otherwise)
-            const size_t bytes = miz_lds_bytes(cfg, mode, imex != 0);
-            if (bytes <= 64 * 1024) continue;
-            for (int grid = 0; grid < 2; ++grid) {
-                KernelFn fn = miz_kernel(cfg.cells, grid, mode, cfg.threads, imex != 0);
-                if (!fn) return hipErrorInvalidValue;
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   (int)bytes);
-                if (e != hipSuccess) return e;
-            }
+            if (cfg.lds_bytes > 64 * 1024)
+                for (int mode = OUT_STATE; mode <= OUT_SAVE; ++mode) {   // (the fused register kernel needs 6T doubles <= 24 KiB)
+                    hipError_t e = raise(miz_kernel(cfg, grid, mode, imex != 0), cfg.lds_bytes);
+                    if (e != hipSuccess) return e;
+                }
+            // the resident fused-K kernels and their savesol! variants (four cells per thread): 160 T bytes
+            const size_t bytes = sizeof(double) * 20 * (size_t)cfg.threads;
+            if (cfg.cells != 4 || bytes <= 64 * 1024) continue;
+            hipError_t e = raise(miz_resident_kernels(grid, cfg.threads, imex != 0), bytes);
+            if (e == hipSuccess) e = raise(miz_resident_save_kernels(grid, cfg.threads, imex != 0), bytes);
+            if (e != hipSuccess) return e;
         }
     return hipSuccess;
 }
 
 bool has_miz_kernel(const LaunchCfg &cfg, int grid_kind, int mode, bool imex) {
-    return miz_kernel(cfg.cells, grid_kind, mode, cfg.threads, imex) != nullptr;
+    return miz_kernel(cfg, grid_kind, mode, imex) != nullptr;
 }
 
 hipError_t launch_miz_step(const StepArgs &a, int grid_kind, int mode, const LaunchCfg &cfg, bool imex, int first, int count,
                            hipStream_t s) {
-    KernelFn fn = miz_kernel(cfg.cells, grid_kind, mode, cfg.threads, imex);
+    KernelFn fn = miz_kernel(cfg, grid_kind, mode, imex);
     if (!fn || first < 0 || count < 1 || first + count > a.ncol) return hipErrorInvalidValue;
     StepArgs b = a;
     b.col0 = first;

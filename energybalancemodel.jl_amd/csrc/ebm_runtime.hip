@@ -548,6 +548,7 @@ int ebm_options_default(ebm_options *opt) {
     opt->prefetch_cols = -1;
     opt->launch_chains = -1;
     opt->integrate_steps_per_launch = -1;
+    opt->fused_state_in_lds = -1;
     return EBM_OK;
 }
 
@@ -575,6 +576,8 @@ int ebm_create_ex(ebm_handle_t *out, int model, int grid, int nlat, int ncol, co
     if (opt.prefetch_cols < -1) return fail(EBM_ERR_ARG, "ebm_create_ex: prefetch_cols must be -1 (default), 0 or a distance");
     if (opt.launch_chains != -1 && opt.launch_chains != 1 && opt.launch_chains != 2)
         return fail(EBM_ERR_ARG, "ebm_create_ex: launch_chains must be -1 (default), 1 or 2");
+    if (opt.fused_state_in_lds < -1 || opt.fused_state_in_lds > 1)
+        return fail(EBM_ERR_ARG, "ebm_create_ex: fused_state_in_lds must be -1 (default), 0 or 1");
     if (opt.integrate_steps_per_launch < -1)
         return fail(EBM_ERR_ARG, "ebm_create_ex: integrate_steps_per_launch must be -1 (default), 1 or a number of steps");
     if (model != EBM_MODEL_MIZ && model != EBM_MODEL_CLASSIC && model != EBM_MODEL_MIZ_IMEX)
@@ -609,6 +612,10 @@ int ebm_create_ex(ebm_handle_t *out, int model, int grid, int nlat, int ncol, co
     }
     h->written_epoch[EBM_F_T0] = 0;                       // the warm start begins at zero, like the reference's (src/miz.jl:47)
     h->num_cus = prop.multiProcessorCount;
+    // more columns than the register kernel runs in one round (it holds one 256-thread workgroup per CU, four of 64 threads:
+    // tests/tools/r3/fused_choice_sweep.py): from there on occupancy beats latency.  The choice changes no bit.
+    h->cfg.fused_in_lds = opt.fused_state_in_lds >= 0 ? opt.fused_state_in_lds != 0
+                                                      : ncol > h->num_cus * std::max(1, 256 / h->cfg.threads);
     // a step of fewer than ~256K cells is launch-bound: replay graphs in ebm_run
     h->use_graph = opt.use_graph >= 0 ? opt.use_graph != 0 : ((long long)nlat * ncol <= 262144);
     {

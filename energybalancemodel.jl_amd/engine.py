@@ -48,15 +48,15 @@ def _env_int(name):
 
 class Engine:
     """``cells_per_thread`` (2 or 4; default 4), ``use_graph`` (True / False; default: by size), ``prefetch_cols`` and
-    ``launch_chains`` (1 or 2; default 1) and ``integrate_steps_per_launch`` (default 64; 1 = ``integrate`` launches every step)
-    are the launch options of ``ebm_create_ex`` (include/ebm_hip.h: struct ebm_options).
+    ``launch_chains`` (1 or 2; default 1), ``integrate_steps_per_launch`` (default 64; 1 = ``integrate`` launches every step)
+    and ``fused_state_in_lds`` (True / False; default: by column count) are the launch options of ``ebm_create_ex`` (include/ebm_hip.h: struct ebm_options).
     The LIBRARY reads no environment variable; this mirror maps EBM_CELLS_PER_THREAD, EBM_GRAPH and
     EBM_PREFETCH_COLS to those options when the corresponding argument is left at None — the knobs of the
     test suite and of the A/B timing scripts under tests/tools/."""
 
     def __init__(self, model: str, grid_kind: str, x, params25, dt: float, ncol: int = 1,
                  device: int = 0, *, cells_per_thread=None, use_graph=None, prefetch_cols=None, launch_chains=None,
-                 integrate_steps_per_launch=None):
+                 integrate_steps_per_launch=None, fused_state_in_lds=None):
         if model not in MODEL:
             raise ValueError(f"unknown model {model!r}: expected 'MIZ', 'Classic' or the extension 'MIZ_IMEX'")
         self.lib = _lib.load()
@@ -84,6 +84,8 @@ class Engine:
             opt.launch_chains = int(launch_chains)
         if integrate_steps_per_launch is not None:
             opt.integrate_steps_per_launch = int(integrate_steps_per_launch)
+        if fused_state_in_lds is not None:
+            opt.fused_state_in_lds = int(bool(fused_state_in_lds))
         h = C.c_void_p()
         gk = GRID["identity"] if grid_kind == "identity" else GRID["nonuniform"]
         check(self.lib.ebm_create_ex(C.byref(h), MODEL[model], gk, self.nlat, self.ncol,

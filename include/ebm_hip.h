@@ -119,6 +119,12 @@ int ebm_create(ebm_handle_t *out, int model, int grid, int nlat, int ncol, const
  *   tails: worth it where a CU holds a single workgroup (meridians of more than 2048 cells) and every chain still fills
  *   the chip several times over (4096 x 2048: 0.1656 -> 0.1594 ms per step).  Columns are independent: bit-identical either
  *   way.  ebm_get_counters counts one launch per chain and step; ignored with graph replay.
+ * fused_state_in_lds: where the fused-K launches (ebm_run_fused) of the reference's step keep the state when both of its
+ *   kernels exist (four cells per thread, meridians of up to 2048 cells): 0 = in registers (fewest LDS round trips: the
+ *   fastest for a few columns), 1 = in LDS (128 registers per lane, so that up to four workgroups share a CU and fill each
+ *   other's barrier stalls: 1.15 ... 1.45 x the throughput on launches of many columns), -1 (default) = in LDS when the
+ *   handle has more columns than the register kernel runs in one round (one 256-thread workgroup per compute unit, four of
+ *   64 threads).  Performance only: the two kernels compute the same bits.
  * integrate_steps_per_launch: how ebm_integrate / ebm_integrate_hemispheric step through the stretches of a year that need
  *   nothing but the annual-mean sums (no raw snapshot, no seasonal snapshot, not a year's last step): -1 (default) and
  *   values > 1 = that many steps fused into one launch with the state resident on the chip and the sums taken from
@@ -131,6 +137,7 @@ typedef struct ebm_options {
     int prefetch_cols;
     int launch_chains;
     int integrate_steps_per_launch;
+    int fused_state_in_lds;
 } ebm_options;
 int ebm_options_default(ebm_options *opt);
 /* ebm_create with explicit options (opt == NULL: the defaults, i.e. exactly ebm_create). */

@@ -63,11 +63,12 @@ struct EBMOptions
     prefetch_cols::Cint         # -1 = default
     launch_chains::Cint         # -1 / 1 = one launch per step; 2 = two independent chains over the two halves of the columns
     integrate_steps_per_launch::Cint   # -1 = 64 steps per launch where integrate needs only the running sums; 1 = every step its own launch
+    fused_state_in_lds::Cint    # -1 = by column count; 0 / 1: fused-K launches keep the state in registers / in LDS (same bits)
 end
 EBMOptions(; cells_per_thread::Integer=0, use_graph::Integer=-1, prefetch_cols::Integer=-1, launch_chains::Integer=-1,
-           integrate_steps_per_launch::Integer=-1) =
+           integrate_steps_per_launch::Integer=-1, fused_state_in_lds::Integer=-1) =
     EBMOptions(Cint(sizeof(EBMOptions)), Cint(cells_per_thread), Cint(use_graph), Cint(prefetch_cols), Cint(launch_chains),
-               Cint(integrate_steps_per_launch))
+               Cint(integrate_steps_per_launch), Cint(fused_state_in_lds))
 
 # One ebm_handle_t.  Every ccall that passes `h.ptr` sits inside `GC.@preserve h`: the pointer alone
 # does not keep `h` alive, and its finalizer calls ebm_destroy.

@@ -153,6 +153,27 @@ def test_fused_run_long_meridians_keep_their_state_in_lds(pkg):
     assert np.any(out[1]["phi"] > 0)
 
 
+def test_fused_kernel_choice_follows_the_column_count_and_changes_no_bit(pkg):
+    """Where both fused-K kernels exist the library picks by column count (more columns than the register kernel runs in one
+    round: state in LDS, for occupancy; fewer: in registers, for latency) unless ebm_options.fused_state_in_lds says
+    otherwise.  A launch of many short meridians: per step, default, forced either way — the same bits."""
+    import torch
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    nlat, ncol, nt = 180, 4 * ncu + 7, 2000
+    st = pkg.SpaceTime("sin", nlat, nt, 1)
+    par = pkg.default_parameters("MIZ")
+    out = {}
+    for name, kw, K in (("single", {}, 1), ("auto", {}, 16), ("registers", dict(fused_state_in_lds=False), 16), ("lds", dict(fused_state_in_lds=True), 16)):
+        with pkg.Engine("MIZ", st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval), st.dt, ncol, device=0, **kw) as eng:
+            eng.set_column_forcing(np.linspace(-3.0, 3.0, ncol))
+            eng.set_time_table(st.t)
+            eng.run(0, 100, None, True, steps_per_launch=K)
+            out[name] = eng.get_state(ALL)
+    for name in ("auto", "registers", "lds"):
+        for k in ALL:
+            assert np.array_equal(out["single"][k], out[name][k], equal_nan=True), (name, k)
+
+
 def test_ensemble_run_fuses_by_default(pkg):
     """EnsembleRun.run lets nothing leave the device between its steps, so it fuses them (64 to a launch) unless told
     otherwise — same bits as one launch per step, a Forcing evaluated per step, for a short and a long meridian and

@@ -1493,7 +1493,7 @@ def test_random_call_sequences_track_the_oracle(pkg, coracle, seed):
 
 @pytest.mark.parametrize("T", list(range(64, 1025, 64)))
 def test_every_workgroup_size(pkg, coracle, T, monkeypatch):
-    """Every workgroup size is its own set of kernel instantiations (408 of the library's 427): for each T = 64 ... 1024, both grid
+    """Every workgroup size is its own set of kernel instantiations (424 of the library's 443): for each T = 64 ... 1024, both grid
     kinds, four cells per thread (nlat = 4T - 1, ragged) and two where that geometry exists (nlat = 2T - 1; T <= 512 and 768),
     the state-only, diagnostic and savesol! kernels, the fused-K kernel of the shape (state in registers, or resident in LDS
     beyond 512 threads and for the extension) and its savesol! variant, the extension — 12 steps from a state with ice and
@@ -1521,8 +1521,10 @@ def test_every_workgroup_size(pkg, coracle, T, monkeypatch):
                 ref.update(diag)
                 got = {}
                 saved = {}
-                for how in ("run", "fused", "integrate", "integrate_fused"):
-                    with pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval), dt, ncol, device=0) as eng:
+                for how in ("run", "fused", "fused_lds", "integrate", "integrate_fused"):
+                    # fused-K with the state in registers where that kernel exists, and in LDS at EVERY size (same bits)
+                    with pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval), dt, ncol, device=0,
+                                    fused_state_in_lds=(how == "fused_lds")) as eng:
                         info = eng.launch_info()
                         assert info["threads"] == T and info["cells_per_thread"] == cells, (info, T, cells)
                         eng.set_state(state)
@@ -1542,12 +1544,13 @@ def test_every_workgroup_size(pkg, coracle, T, monkeypatch):
                                     assert np.array_equal(out["summer"][vi, 0], out["raw"][vi, 8], equal_nan=True)
                         else:
                             eng.set_time_table(t64)
-                            eng.run(30, nsteps, None, True, steps_per_launch=(5 if how == "fused" else 1))
+                            eng.run(30, nsteps, None, True, steps_per_launch=(5 if how.startswith("fused") else 1))
                             got[how] = eng.get_state(ALL)
                             cnt = eng.counters()
                             assert cnt["launches"] == (nsteps if how == "run" else 3), (how, cnt)   # every shape has a fused-K kernel
                 for k in ALL:
                     assert np.array_equal(got["run"][k], got["fused"][k], equal_nan=True), (T, cells, kind, model, k)
+                    assert np.array_equal(got["run"][k], got["fused_lds"][k], equal_nan=True), (T, cells, kind, model, k)
                     assert np.array_equal(got["run"][k], got["integrate"][k], equal_nan=True), (T, cells, kind, model, k)
                     assert np.array_equal(got["run"][k], got["integrate_fused"][k], equal_nan=True), (T, cells, kind, model, k)
                 for k in ("winter", "summer", "avg"):

@@ -164,7 +164,7 @@ def test_options_are_arguments_not_environment(pkg, monkeypatch):
     opt = L.Options()
     assert lib.ebm_options_default(C.byref(opt)) == 0
     assert (opt.struct_bytes, opt.cells_per_thread, opt.use_graph, opt.prefetch_cols, opt.launch_chains,
-            opt.integrate_steps_per_launch) == (C.sizeof(L.Options), 0, -1, -1, -1, -1)
+            opt.integrate_steps_per_launch, opt.fused_state_in_lds) == (C.sizeof(L.Options), 0, -1, -1, -1, -1, -1)
     rc, h = create(opt)
     assert rc == 0 and info(h)[:2] == [64, 4]
     lib.ebm_destroy(h)
@@ -179,7 +179,7 @@ def test_options_are_arguments_not_environment(pkg, monkeypatch):
     assert rc == 0 and info(h)[:2] == [128, 2]
     lib.ebm_destroy(h)
     for field, bad in (("cells_per_thread", 3), ("use_graph", 2), ("prefetch_cols", -2), ("struct_bytes", 0), ("launch_chains", 3),
-                       ("integrate_steps_per_launch", -2)):
+                       ("integrate_steps_per_launch", -2), ("fused_state_in_lds", 2)):
         o = L.Options()
         lib.ebm_options_default(C.byref(o))
         setattr(o, field, bad)
