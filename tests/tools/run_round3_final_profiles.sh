@@ -45,7 +45,10 @@ for W in "miz_4096x2048 --launch-chains 2" "miz_4096x2048_step" "miz_4096x2048_s
          "miz_1024x512x32_integrate --steps 1024 --repeats 3 --integrate-steps-per-launch 256" "miz_2048x4096" \
          "classic_1024x512 --steps 2000" "classic_1024x512 --steps 2048 --steps-per-launch 64" "miz_imex_4096x2048" "miz_imex_4096x2048 --launch-chains 2" \
          "miz_4096x2048 --steps-per-launch 16" "miz_4096x2048 --steps 1024 --steps-per-launch 64" "miz_4096x2048 --steps 1024 --steps-per-launch 256" \
-         "miz_2048x4096 --steps 1024 --steps-per-launch 64" "miz_imex_4096x2048 --steps-per-launch 16" "miz_imex_4096x2048 --steps 1024 --steps-per-launch 64"; do
+         "miz_2048x4096 --steps 1024 --steps-per-launch 64" "miz_2048x4096 --steps 1024 --steps-per-launch 64 --fused-state registers" \
+         "miz_1024x512x32 --steps 512 --steps-per-launch 64" "miz_1024x512x32 --steps 512 --steps-per-launch 64 --fused-state registers" \
+         "miz_180x8192 --steps 512 --steps-per-launch 64 --fused-state registers" \
+         "miz_imex_4096x2048 --steps-per-launch 16" "miz_imex_4096x2048 --steps 1024 --steps-per-launch 64"; do
   python bench.py --workload $W --cpu-budget 0 >> $O/other_workloads.jsonl 2>> $O/other_workloads.err
 done
 EBM_BENCH_BACKEND=gloo python bench.py --gpus 2 --workload miz_1024x512x32 --steps 50 --cpu-budget 0 > $O/bench_two_ranks_one_gpu.log 2>&1
