@@ -1,7 +1,8 @@
 """Seeded fuzz of the fused paths against one launch per step, GPU only (no oracle: this is about identity, and the per-step path
 is what the oracle is compared with elsewhere): random meridian length 2 ... 4096, grid kind, model (MIZ / MIZ_IMEX), cells per
 thread, the loose random states of test_randomized_states_one_step (open water, thin and thick ice, phi = 0 / 1 / between,
-floes at Dmin / Dmax / 0, inconsistent Ei, random warm starts; every sixth seed keeps Inf / NaN in), random K and run length.
+floes at Dmin / Dmax / 0, inconsistent Ei, random warm starts; every sixth seed keeps Inf / NaN in), random K and run length,
+random choice of the fused-K kernel where both exist (ebm_options.fused_state_in_lds).
 Compared bit for bit: ebm_run vs ebm_run_fused (state and diagnostics), ebm_integrate with one launch per step vs fused
 stretches (final state, winter, summer, avg), and the solve counters.
     python tests/tools/fuzz_fused.py [first] [count]"""
@@ -47,10 +48,12 @@ for seed in range(first, first + count):
     tt = np.array([pkg.cos2pit((i + 0.5) * dt) for i in range(t0, t0 + 64)])
     f_steps = rng.uniform(-2.0, 2.0, nsteps)
     wi, si = 2, max(4, nsteps // 2)
+    in_lds = [None, False, True][int(rng.integers(0, 3))]                   # which fused-K kernel where both exist
     out = {}
     for how in ("run", "run_fused", "integrate", "integrate_fused"):
         with pkg.Engine(model, st.grid_kind, st.x, pkg.engine.param_vector(par, pkg.default_parval), dt, ncol, device=0,
-                        cells_per_thread=cells, integrate_steps_per_launch=(1 if how == "integrate" else K)) as eng:
+                        cells_per_thread=cells, integrate_steps_per_launch=(1 if how == "integrate" else K),
+                        fused_state_in_lds=in_lds) as eng:
             eng.set_state(state)
             eng.set_column_forcing(fcol)
             if how.startswith("run"):
@@ -61,7 +64,7 @@ for seed in range(first, first + count):
                 eng.set_time_table(tt[:nsteps])
                 saved = eng.integrate(nsteps, 1, f_steps, True, wi, si, ("E", "T", "phi", "Ti"), want_raw=False)
             out[how] = (eng.get_state(ALL), saved, eng.counters())
-    what = f"seed {seed}: {model} {kind} {nlat}x{ncol}, {cells} cells per thread, K = {K}, {nsteps} steps"
+    what = f"seed {seed}: {model} {kind} {nlat}x{ncol}, {cells} cells per thread, K = {K}, {nsteps} steps, fused state in LDS: {in_lds}"
     fails = []
     for a, b in (("run", "run_fused"), ("run", "integrate"), ("integrate", "integrate_fused")):
         fails += [f"{b}:{k}" for k in ALL if not np.array_equal(out[a][0][k], out[b][0][k], equal_nan=True)]
