@@ -21,7 +21,8 @@
 //                                       registers (annual-mean sums, raw snapshots); IMEX: the implicit-diffusion
 //                                       extension (one more tridiagonal solve per step, see include/ebm_hip.h)
 //   miz_fused_kernel<C, GRID, T>        K steps per launch, the whole state in registers (<= 512 threads; 768 with C = 2)
-//   miz_resident_kernel<GRID, T, IMEX>  K steps per launch, the state resident in LDS (more than 512 threads; the extension)
+//   miz_resident_kernel<GRID, T, IMEX, SAVE>  K steps per launch, the state resident in LDS (more than 512 threads; the extension;
+//                                       launches of many columns at any size; SAVE: with savesol!'s sums, for ebm_integrate)
 //   classic_step_kernel<C, MODE>        WE15 model: single step / savesol! / K steps per launch
 //   diffusion_kernel<GRID>              the diffusion operator on its own (ebm_diffusion)
 //   finish_mean, hemispheric_mean, mask_from_t0, derive_params, divide: small helpers
@@ -1205,7 +1206,8 @@ __global__ void __launch_bounds__(TT) miz_fused_kernel(const StepArgs a) {
 }
 
 // Fused-K MIZ stepping for the meridians the register kernel above cannot hold (more than kFusedRegThreads threads
-// at four cells per thread: 2049 ... 4096 cells) and for the implicit-diffusion extension at every size: a.nfused steps
+// at four cells per thread: 2049 ... 4096 cells), for the implicit-diffusion extension at every size, and for launches of
+// many shorter meridians (LaunchCfg::fused_in_lds: at 128 VGPRs several workgroups share a CU): a.nfused steps
 // in one launch with the state RESIDENT IN LDS — Ei, Ew, h, D of every cell (cell i of thread t at i*T + t, 16 T doubles),
 // phi in registers.  What the per-step kernel spends its LDS on is cut to fit beside that: the solve runs in 4 T doubles
 // instead of 6 T (partition_solve_r<COMPACT>: one more barrier), the halo exchanges go through the lane crossbar and 32
@@ -1213,7 +1215,7 @@ __global__ void __launch_bounds__(TT) miz_fused_kernel(const StepArgs a) {
 // formed again for the cell updates (one division) instead of being stashed: 20 T doubles = exactly the CU's 160 KiB at
 // T = 1024.  Global memory is touched at the start (state in), at the end (state out, diagnostics of the last step if
 // write_diag) and by the per-step table loads (L2 hits).  Every step performs the operations of miz_step_kernel in the
-// same order on the same values: bit-identical results (tests: test_resident_fused_run_equals_single_steps).
+// same order on the same values: bit-identical results (tests: test_fused_run_equals_single_steps, test_every_workgroup_size).
 //
 // SAVE: savesol!'s annual-mean running sums taken from every step of the launch (save_pair, as in miz_step_kernel<OUT_SAVE>:
 // the same per-cell sum in step order, the same bits) — what ebm_integrate launches for the stretches of a year that need
