@@ -64,7 +64,11 @@ struct ebm_ctx {
     int num_cus = 0;
     int prefetch = 0;                 // L2 prefetch distance of the MIZ kernel, columns (0 = off)
     double *hm_dev = nullptr;         // ebm_hemispheric_mean: per-column results on the device
-    ebm::StepSched *fused_sched = nullptr;   // per-step scalars of the fused-K launches (kFusedTable entries)
+    // per-step scalars of the fused-K launches: two device tables of kFusedTable entries used in turn, each with the event
+    // that marks the end of the launches that read it — a table is refilled only after that event, so consecutive fused
+    // calls neither wait for each other nor synchronise the stream
+    struct SchedTable { ebm::StepSched *dev = nullptr; hipEvent_t done = nullptr; bool in_use = false; } sched_tab[2];
+    int sched_next = 0;
     int integrate_spl = 64;                  // ebm_options::integrate_steps_per_launch (1 = one launch per step)
     // hipGraph replay for launch-bound shapes (small grids): kGraphSteps step kernels per replay
     ebm::StepSched *sched_dev = nullptr;
@@ -685,7 +689,10 @@ int ebm_destroy(ebm_handle_t h) {
     if (h->p_dev) (void)hipFree(h->p_dev);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->sched_dev) (void)hipFree(h->sched_dev);
-    if (h->fused_sched) (void)hipFree(h->fused_sched);
+    for (auto &tb : h->sched_tab) {
+        if (tb.dev) (void)hipFree(tb.dev);
+        if (tb.done) (void)hipEventDestroy(tb.done);
+    }
     if (h->hm_dev) (void)hipFree(h->hm_dev);
     if (h->amask) (void)hipFree(h->amask);
     if (h->fcol) (void)hipFree(h->fcol);
@@ -996,7 +1003,6 @@ int ebm_run(ebm_handle_t h, long long first_step, int nsteps, const double *f_st
 static int fused_range(ebm_ctx *h, long long tab_first, long long clock_first, int nsteps, const double *f_steps, int diag_last,
                        int steps_per_launch, const SaveTarget *save) {
     const long long first_step = clock_first;
-    if (!h->fused_sched) HIPCHK(hipMalloc(&h->fused_sched, sizeof(ebm::StepSched) * kFusedTable));
     const long long nt = (long long)h->ttab.size();
     std::vector<ebm::StepSched> sched;
     for (int s0 = 0; s0 < nsteps; s0 += kFusedTable) {
@@ -1009,12 +1015,19 @@ static int fused_range(ebm_ctx *h, long long tab_first, long long clock_first, i
             sched[i].ft = f_steps ? f_steps[s0 + i] : 0.0;
             sched[i].tyear = year_time(h, first_step + s0 + i);
         }
-        // the launches of the previous batch still read the table: drain them before it is refilled
-        HIPCHK(hipStreamSynchronize(main_stream(h)));
-        HIPCHK(hipMemcpy(h->fused_sched, sched.data(), sizeof(ebm::StepSched) * (size_t)n, hipMemcpyHostToDevice));
+        // the table used two batches ago: its launches must have ended before it is refilled (normally long since).  The copy is
+        // synchronous for the host but not ordered with the handle's (non-blocking) streams.
+        auto &tb = h->sched_tab[h->sched_next];
+        h->sched_next ^= 1;
+        if (!tb.dev) {
+            HIPCHK(hipMalloc(&tb.dev, sizeof(ebm::StepSched) * kFusedTable));
+            HIPCHK(hipEventCreateWithFlags(&tb.done, hipEventDisableTiming));
+        }
+        if (tb.in_use) HIPCHK(hipEventSynchronize(tb.done));
+        HIPCHK(hipMemcpy(tb.dev, sched.data(), sizeof(ebm::StepSched) * (size_t)n, hipMemcpyHostToDevice));
         for (int i = 0; i < n; i += steps_per_launch) {
             ebm::StepArgs a = base_args(h);
-            a.sched = h->fused_sched;
+            a.sched = tb.dev;
             a.slot = i;
             a.nfused = std::min(steps_per_launch, n - i);
             a.prefetch = 0;
@@ -1030,6 +1043,8 @@ static int fused_range(ebm_ctx *h, long long tab_first, long long clock_first, i
             note_steps(h, a.nfused, first_step + s0 + i + a.nfused - 1, a.write_diag != 0);
             if (a.write_diag && h->model == EBM_MODEL_MIZ) h->diag_split = false;      // the fused kernel stores them in the natural layout
         }
+        HIPCHK(hipEventRecord(tb.done, main_stream(h)));     // (both launch chains, joined)
+        tb.in_use = true;
         h->n_steps += n;
         h->clock = first_step + s0 + n;
     }

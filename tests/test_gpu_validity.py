@@ -268,8 +268,9 @@ def test_two_launch_chains_wait_for_what_the_handle_did_before(pkg):
     par = pkg.default_parameters("MIZ")
     fcol = np.linspace(-2.0, 2.0, ncol)
     out = {}
-    # (one launch per step: the fused stretches of ebm_integrate begin with a stream synchronisation — the upload of their
-    #  table of step scalars — which would hide a missing wait; the fused default is compared as well)
+    # (with one launch per step everywhere, and with the default: the stretches between the year ends fused.  Up to a late
+    #  commit of round 3 every fused stretch began with a stream synchronisation, which hid a missing wait from this test:
+    #  profiles/r03_mutants_final.log)
     for chains, spl in ((1, 1), (2, 1), (2, None)):
         with make_engine(pkg, "MIZ", st, par, ncol, launch_chains=chains, use_graph=False, integrate_steps_per_launch=spl) as eng:
             eng.set_column_forcing(fcol)
