@@ -414,6 +414,28 @@ def test_bench_gpus_n_refuses_without_devices():
     assert r.returncode != 0 and "must agree" in r.stderr and r.stdout.strip() == ""
 
 
+def test_bench_names_the_kernel_the_library_picks():
+    """bench.py's roofline block names the kernel of a workload by the library's own rule (csrc/ebm_kernels.hip:
+    fused_state_in_lds; csrc/ebm_runtime.hip: ebm_create_ex): per-step kernel at K = 1; fused with the state in registers for
+    a few columns of up to 512 threads and for two cells per thread; resident in LDS for longer meridians, for the
+    extension, for more columns than the register kernel runs in one round, or when told so."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    name = bench.kernel_name
+    t256 = {"threads": 256, "cells_per_thread": 4}
+    assert name("Classic", 64, t256) == "classic_step_kernel"
+    assert name("MIZ", 1, t256, 16384) == "miz_step_kernel"
+    assert name("MIZ", 64, t256, 256, 256) == "miz_fused_kernel" and name("MIZ", 64, t256, 257, 256) == "miz_resident_kernel"
+    assert name("MIZ", 64, {"threads": 64, "cells_per_thread": 4}, 1024, 256) == "miz_fused_kernel"
+    assert name("MIZ", 64, {"threads": 64, "cells_per_thread": 4}, 1025, 256) == "miz_resident_kernel"
+    assert name("MIZ", 64, t256, 16384, 256, False) == "miz_fused_kernel" and name("MIZ", 64, t256, 1, 256, True) == "miz_resident_kernel"
+    assert name("MIZ", 64, {"threads": 1024, "cells_per_thread": 4}, 1, 256, False) == "miz_resident_kernel"
+    assert name("MIZ_IMEX", 64, {"threads": 64, "cells_per_thread": 4}, 1, 256, False) == "miz_resident_kernel"
+    assert name("MIZ", 64, {"threads": 768, "cells_per_thread": 2}, 9999, 256, True) == "miz_fused_kernel"
+
+
 def test_visible_gpu_count_reads_the_driver_topology(pkg, tmp_path, monkeypatch):
     """Launch decisions count GPUs without initialising HIP: KFD topology nodes with SIMDs, narrowed by the
     *_VISIBLE_DEVICES variables the runtime honours."""
